@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- PCApply GB/s (+ KSP iterations/s) of the MI355X SPIKE banded preconditioner.
+
+Metric (BASELINE.json): "PCApply GB/s + KSP iters/sec, N=4M half-bw=128 fp64, 1/2/4/8 GPU".
+A "step" is one PCApply (spike_apply through the C-ABI) on device-resident vectors of the synthetic
+banded system of SURVEY.md 8d (N = 4*2^20, K = 128, delta = 1.2, seed 12345), generated on the GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; the N-row system is split into N contiguous row blocks (strong scaling: total work
+fixed), each rank factors its own partitions, and the rank-boundary interface systems are assembled by an RCCL
+allgather inside the library (spike_comm_init).
+
+Algorithmic bytes per PCApply (SURVEY.md 8d / BASELINE.md 3):
+    BYTES(N,K,p) = p*[(2K+1)*N*8 + 2*N*8] + (P-1)*[(2K)^2 + 4K]*8      p = 1 decoupled, p = 2 coupled
+`value` = BYTES(N,K,p of the benchmarked variant) / time.  The JSON also carries the strict one-pass
+figure (BYTES(N,K,1)/time) and the other variant.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def alg_bytes(N, K, p, P):
+    return p * ((2 * K + 1) * N * 8 + 2 * N * 8) + max(P - 1, 0) * ((2 * K) ** 2 + 4 * K) * 8
+
+
+def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
+    """The oracle (CPU port of the same algorithm) timed on this host, on a bounded sample."""
+    import numpy as np
+    import oracle as O
+    try:
+        L = O.lib(O.build(native=True))
+    except Exception:
+        L = O.lib()
+    N = budget_rows
+    P = max(1, N // rows_per_part)
+    band = O.gen_band(N, K, L=L)
+    f = O.gen_vec(N)
+    t0 = time.perf_counter()
+    sp = O.Spike(band, P, L=L)
+    t_setup = time.perf_counter() - t0
+    sp.apply(f, variant)
+    reps, t = 0, 0.0
+    t0 = time.perf_counter()
+    while reps < 3 or (t < 3.0 and reps < 50):
+        sp.apply(f, variant)
+        reps += 1
+        t = time.perf_counter() - t0
+    per = t / reps
+    p = 2 if variant == 1 else 1
+    return {
+        "value": alg_bytes(N, K, p, P) / per / 1e9, "unit": "GB/s", "cores": int(L.orc_num_threads()), "kind": "port",
+        "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition as on the GPU), "
+                  "%s variant, %d applies, setup %.1f s not timed" % (N, K, P, rows_per_part,
+                                                                     "coupled" if variant else "decoupled", reps, t_setup),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4 * 2 ** 20)
+    ap.add_argument("--k", type=int, default=128)
+    ap.add_argument("--partitions", type=int, default=0, help="per GPU; 0 = auto")
+    ap.add_argument("--variant", default="coupled", choices=["coupled", "decoupled"])
+    ap.add_argument("--delta", type=float, default=1.2)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ksp", action="store_true")
+    ap.add_argument("--ksp-iters", type=int, default=30)
+    args = ap.parse_args()
+
+    import torch
+    import spike_petsc_amd as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    N, K = args.n, args.k
+    # contiguous row blocks on 64-row boundaries
+    nblk = (N + 63) // 64
+    r0 = (nblk * rank // world) * 64
+    r1 = N if rank == world - 1 else (nblk * (rank + 1) // world) * 64
+    n_local = r1 - r0
+
+    sp = S.Spike(partitions=args.partitions, variant=args.variant, profile=True)
+    if world > 1:
+        uid = torch.zeros(S.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(S.unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, 0)
+        sp.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+
+    band = S.gen_band_device(N, K, seed=12345, delta=args.delta, row0=r0, nrows=n_local)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sp.set_option("keep_band", 1)
+    sp.setup_band(band, n_global=N, row0=r0)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    del band
+    info = sp.info()
+    P_total = info.P_local * world
+
+    u = torch.ones(n_local, dtype=torch.float64, device="cuda")
+    b = sp.matvec(u)          # rhs = A*1, as /root/reference/src/testbed2.c:120-122
+    x = torch.empty_like(b)
+    for _ in range(args.warmup):
+        sp.apply(b, x)
+    barrier()
+    t0 = time.perf_counter()
+    sweep_ms, sweep_launches = 0.0, 0
+    for _ in range(args.steps):
+        sp.apply(b, x)
+    barrier()
+    dt = time.perf_counter() - t0
+    # kernel time of the LAST apply from HIP events recorded on the handle's stream
+    sweep_ms, sweep_launches = sp.last_sweep_ms()
+    err = float((x - u).abs().max())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    p = 2 if args.variant == "coupled" else 1
+    gbps = alg_bytes(N, K, p, P_total) / (dt / args.steps) / 1e9
+    gbps_1 = alg_bytes(N, K, 1, P_total) / (dt / args.steps) / 1e9
+
+    # dominant kernel: k_sweep (forward + backward launch = one pass over the factors of the local rows)
+    n_pass = max(sweep_launches // 2, 1)
+    pass_bytes = (2 * K + 1) * n_local * 8 + 2 * n_local * 8
+    pass_ms = sweep_ms / n_pass if sweep_launches else float("nan")
+    achieved = pass_bytes / (pass_ms * 1e-3) / 1e9 if sweep_launches else float("nan")
+
+    # Krylov: fixed number of left-preconditioned GMRES(30) iterations (rtol=0 so it never stops early)
+    ksp = None
+    if not args.no_ksp:
+        xg = torch.zeros_like(b)
+        sp.set_option("profile", 0)
+        sp.gmres(b, xg, restart=30, rtol=0.0, maxit=3)  # warm-up (allocates the Krylov basis)
+        xg.zero_()
+        barrier()
+        it, rn, ms, ok = sp.gmres(b, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
+        barrier()
+        tk = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        ksp = {"iters": it, "solve_ms": float(tk.item()), "iters_per_sec": it / (float(tk.item()) * 1e-3)}
+        # and one real solve to the reference's tolerance (src/makefile:18: rtol 1e-5, max_it 500)
+        xg.zero_()
+        it2, rn2, ms2, ok2 = sp.gmres(b, xg, restart=30, rtol=1e-5, maxit=500)
+        ksp.update({"converged_iters_rtol1e-5": it2, "converged": bool(ok2), "error_inf": float((xg - u).abs().max())})
+
+    if rank == 0:
+        out = {
+            "metric": "PCApply GB/s", "value": gbps, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "banded N=%d half-bw=%d fp64, SPIKE %s, %d partitions (%d/GPU), delta=%.2f, seed 12345"
+                                   % (N, K, args.variant, P_total, info.P_local, args.delta),
+                       "N": N, "K": K, "partitions": P_total, "variant": args.variant,
+                       "passes_over_factors": p, "rows_per_partition": n_local // info.P_local},
+            "GBps_single_pass_bytes": gbps_1,
+            "max_abs_error_vs_exact_solution": err,
+            "setup_s": setup_s,
+            "ksp": ksp,
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "alg_bytes_per_pass": pass_bytes, "pass_ms": pass_ms},
+        }
+        if not args.no_cpu and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(K, max(n_local // info.P_local, 64), 1 if args.variant == "coupled" else 0)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * spike_mi355.h -- C-ABI of the MI355X-native SPIKE banded preconditioner engine.
+ *
+ * This library fills the one slot the reference leaves to "whatever PETSc provides":
+ * the inner PC of PCBANDED.  Each entry point names the reference interface it
+ * replaces (paths relative to /root/reference):
+ *
+ *   spike_create / spike_destroy   PCCreate(...,&b->pc) src/matbanded.c:278, PCDestroy(&b->pc) :142
+ *   spike_set_option               PCSetFromOptions(b->pc) src/matbanded.c:159 (options prefix "banded_", :281)
+ *   spike_setup_band               PCSetOperators(b->pc,pc->mat,b->B)+PCSetUp(b->pc) src/matbanded.c:176-178
+ *   spike_setup_csr                MatCreateSubMatrixBanded + PCSetUp(b->pc)  src/matbanded.c:22-107,174-178
+ *   spike_apply                    PCApply(b->pc,x,y) src/matbanded.c:190   (the metric's "PCApply")
+ *   spike_reset                    PCReset(b->pc) src/matbanded.c:127
+ *   spike_view                     PCView(b->pc,viewer) src/matbanded.c:207
+ *   spike_gmres                    KSPSolve(ksp,b,x) src/testbed2.c:128 with -ksp_type gmres (src/makefile:18)
+ *   spike_comm_*                   the communicator of the PC, PetscObjectComm((PetscObject)pc) src/matbanded.c:278
+ *
+ * Plain C types only: pointers, sizes, ints.  All functions return 0 on success or a
+ * negative spike_status; spike_last_error() gives the message (the reference's
+ * PetscErrorCode/SETERRQ convention, src/matbanded.c:95).
+ *
+ * Band layout ("diagonal-major"):  band[d*ld + i] = A[i, i + d - K],  d in [0,2K], i in [0,n).
+ * Entries whose column falls outside [0,N) are ignored.  fp64 throughout.
+ *
+ * Threading: one host thread drives one handle; one process per GPU.  Multi-GPU jobs
+ * give every rank a handle that owns a contiguous block of rows, and the ranks are
+ * joined with spike_comm_init (RCCL).
+ */
+#ifndef SPIKE_MI355_H
+#define SPIKE_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spike_handle_s *spike_handle;
+
+typedef enum {
+    SPIKE_OK = 0,
+    SPIKE_ERR_ARG = -1,       /* bad argument / unsupported size */
+    SPIKE_ERR_HIP = -2,       /* HIP runtime error (message in spike_last_error) */
+    SPIKE_ERR_STATE = -3,     /* call order (apply before setup ...) */
+    SPIKE_ERR_PARTITION = -4, /* P does not fit N (needs >= P 64-row blocks and rows/partition >= K) */
+    SPIKE_ERR_COMM = -5,      /* RCCL error */
+    SPIKE_ERR_SINGULAR = -6,  /* an interface system is singular */
+    SPIKE_ERR_NOMEM = -7
+} spike_status;
+
+#define SPIKE_VARIANT_DECOUPLED 0 /* block-Jacobi over the P partitions: one pass over the factors */
+#define SPIKE_VARIANT_COUPLED 1   /* truncated SPIKE: pass, interface solves, corrected pass        */
+
+#define SPIKE_UNIQUE_ID_BYTES 128
+
+typedef struct {
+    int64_t n_local;       /* rows owned by this handle */
+    int64_t n_global;      /* rows of the whole system  */
+    int64_t row0;          /* first global row owned    */
+    int32_t K;             /* half-bandwidth given      */
+    int32_t Kp;            /* half-bandwidth the sweep kernels stream (K padded) */
+    int32_t P_local;       /* partitions on this handle */
+    int32_t P_global;
+    int32_t variant;
+    int32_t rows_per_block;  /* R */
+    int32_t waves_per_chain; /* NW */
+    int32_t nranks, rank;
+    int64_t nboost;          /* pivots boosted during factorisation */
+    int64_t factor_bytes;    /* bytes of packed factors streamed by ONE pass (L tiles + U tiles + 1/diag) */
+    int64_t iface_bytes;     /* bytes of interface matrices read per coupled apply */
+    double setup_ms;         /* wall time of the last setup (device work, synchronised) */
+    int32_t k_extracted;     /* spike_setup_csr: chosen half-bandwidth (matbanded.c:104) */
+    double frac_extracted;   /* spike_setup_csr: achieved norm fraction (matbanded.c:105) */
+} spike_info;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int spike_create(spike_handle *h);
+int spike_destroy(spike_handle h);
+int spike_reset(spike_handle h); /* drop the factors, keep options and communicator */
+const char *spike_last_error(spike_handle h);
+
+/* keys: "partitions" (int >=1, or 0 = auto), "variant" ("decoupled"|"coupled"|0|1),
+ *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1)    */
+int spike_set_option(spike_handle h, const char *key, const char *value);
+/* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */
+int spike_set_stream(spike_handle h, void *hip_stream);
+
+/* ---- multi-GPU (one process per GPU; optional) ------------------------------------ */
+int spike_comm_unique_id(char id[SPIKE_UNIQUE_ID_BYTES]); /* rank 0 creates, host code broadcasts */
+/* Joins nranks handles.  Must precede setup.  row0/n_global describe this rank's row block. */
+int spike_comm_init(spike_handle h, int nranks, int rank, const char id[SPIKE_UNIQUE_ID_BYTES]);
+
+/* ---- setup ------------------------------------------------------------------------- */
+/* Factor the local rows [row0,row0+n_local) of an n_global system.  The local band holds the
+ * local rows only (ld >= n_local) but with GLOBAL column meaning, so entries that couple to a
+ * neighbouring rank sit in their natural band slots.  Single GPU: row0=0, n_local=n_global.
+ * on_device != 0: band is a device pointer.                                               */
+int spike_setup_band(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, int K,
+                     const double *band, int64_t ld, int on_device);
+
+/* CSR entry (single rank): band extraction with the reference's rule, then spike_setup_band.
+ * kmax/frac as PCBANDED's -pc_banded_kmax/-pc_banded_frac (defaults 50 / 0.95).
+ * ia/ja are 0-based int64 host arrays.                                                     */
+int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
+                    int kmax, double frac, int *k_out, double *frac_out);
+
+/* ---- apply --------------------------------------------------------------------------- */
+/* y = M^{-1} x on the local rows.  x != y.  on_device != 0: device pointers, asynchronous on
+ * the handle's stream; otherwise host pointers, synchronous.                               */
+int spike_apply(spike_handle h, const double *x, double *y, int on_device);
+
+/* ---- Krylov caller ---------------------------------------------------------------------- */
+/* Left-preconditioned GMRES(restart) on the band given at setup (keep_band=1) with this handle
+ * as preconditioner (use_pc=0: unpreconditioned).  b,x device pointers of n_local doubles; x
+ * holds the initial guess on entry.  Convergence: preconditioned residual <= rtol * initial.
+ * Returns 0 converged, 1 hit maxit, <0 error.                                              */
+int spike_gmres(spike_handle h, const double *b, double *x, int restart, double rtol, int maxit, int use_pc,
+                int *iters, double *rnorm, double *solve_ms);
+
+/* ---- helpers (device) ----------------------------------------------------------------------- */
+/* y = A x with the band kept at setup (device pointers, local rows; halo via RCCL when nranks>1) */
+int spike_band_matvec(spike_handle h, const double *x, double *y);
+/* the synthetic system of SURVEY.md 8d, generated in place on the device (bit-identical to the
+ * CPU oracle's generator): rows [row0,row0+nrows) of an n_global band, ld >= nrows            */
+int spike_gen_band(void *hip_stream, int64_t n_global, int K, uint64_t seed, double delta, int64_t row0,
+                   int64_t nrows, double *band_dev, int64_t ld);
+
+/* ---- introspection --------------------------------------------------------------------------- */
+int spike_get_info(spike_handle h, spike_info *info);
+int spike_view(spike_handle h, char *buf, size_t buflen);
+/* test hooks: copy the K x K spike tips of the local interfaces to host (row-major) */
+int spike_get_tips(spike_handle h, double *Vb, double *Wt);
+/* timing hook: average device time (ms) of the sweep kernels of the last spike_apply, from
+ * HIP events recorded on the handle's stream (valid after spike_set_option(h,"profile","1")) */
+int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPIKE_MI355_H */

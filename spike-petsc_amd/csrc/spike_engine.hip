@@ -1,0 +1,793 @@
+// spike_engine.hip -- C-ABI of include/spike_mi355.h on top of the kernels in spike_kernels.hip.
+//
+// Lifecycle mirrors the inner PC of the reference's PCBANDED (/root/reference/src/matbanded.c):
+//   spike_create (:278 PCCreate) -> spike_set_option (:159) -> spike_setup_* (:174-178)
+//   -> spike_apply x #Krylov iterations (:190) -> spike_reset (:127) / spike_destroy (:142).
+// There is NO CPU fallback: every entry point that computes needs a HIP device and fails
+// with SPIKE_ERR_HIP otherwise.
+#include "../../include/spike_mi355.h"
+#include "spike_internal.h"
+
+#include <dlfcn.h>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace spike;
+
+// ---- RCCL through dlopen: the library has no link-time dependency on librccl ----------------
+typedef struct ncclComm *ncclComm_t_;
+typedef struct { char internal[128]; } ncclUniqueId_;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
+    int (*CommInitRank)(ncclComm_t_ *, int, ncclUniqueId_, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather && AllReduce; }
+};
+static RcclApi g_rccl;
+static bool rccl_load()
+{
+    if (g_rccl.ok()) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return false;
+    g_rccl.GetUniqueId = (int (*)(ncclUniqueId_ *))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(ncclComm_t_ *, int, ncclUniqueId_, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    return g_rccl.ok();
+}
+enum { NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_SUM = 0 };
+
+// ---- handle ---------------------------------------------------------------------------------------
+struct spike_handle_s {
+    // options
+    int opt_partitions = 0;
+    int variant = SPIKE_VARIANT_COUPLED;
+    double boost_rel = 1e-10;
+    int keep_band = 1;
+    int profile = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // communicator
+    int nranks = 1, rank = 0;
+    ncclComm_t_ comm = nullptr;
+    // problem
+    bool ready = false;
+    int64_t n_global = 0, row0 = 0, n = 0;
+    int K = 0, P = 0;
+    SweepCfg cfg{64, 32, 1};
+    std::vector<ChainDesc> chains;
+    std::vector<GroupDesc> groups;
+    int64_t ntiles = 0, maxsteps = 0;
+    int nif = 0;
+    // device buffers
+    double *dA = nullptr;
+    bool ownA = false;
+    int64_t ldA = 0;
+    double *dLt = nullptr, *dUt = nullptr, *dDinv = nullptr, *dY = nullptr, *dTmp = nullptr;
+    ChainDesc *dChains = nullptr;
+    GroupDesc *dGroups = nullptr;
+    IfaceDesc *dIfs = nullptr;
+    double *dWt = nullptr, *dVb = nullptr;                // per chain, row-major K x K
+    double *dWT = nullptr, *dVT = nullptr, *dST = nullptr;  // per interface, column-major
+    double *dBT = nullptr, *dCT = nullptr;                // per chain, column-major
+    double *dCorrTop = nullptr, *dCorrBot = nullptr;      // per chain, K
+    double *dTips = nullptr;                              // per chain [gt(K) | gb(K)]
+    double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
+    double *dHalo = nullptr;                              // matvec halo: [K left | K right]
+    double *dXh = nullptr;                                // x extended by halos (n + 2K)
+    // gmres workspace
+    double *dV = nullptr, *dW = nullptr, *dZ = nullptr, *dDots = nullptr, *dCoef = nullptr;
+    int gm_restart = 0;
+    // info
+    int64_t nboost = 0;
+    double setup_ms = 0.0;
+    int k_extracted = -1;
+    double frac_extracted = 0.0;
+    // profiling of the sweep kernels
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    int nev = 0;
+};
+
+static int fail(spike_handle h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return fail(h, SPIKE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCLCHK(call)                                                                                        \
+    do {                                                                                                     \
+        int r_ = (call);                                                                                     \
+        if (r_ != 0) return fail(h, SPIKE_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return hipMalloc((void **)p, count * sizeof(T));
+}
+
+static void free_factors(spike_handle h)
+{
+    auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    if (h->ownA) F(h->dA); else h->dA = nullptr;
+    h->ownA = false;
+    F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
+    F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
+    F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dHalo); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
+    h->gm_restart = 0;
+    h->ready = false;
+    h->chains.clear();
+    h->groups.clear();
+}
+
+extern "C" int spike_create(spike_handle *out)
+{
+    if (!out) return SPIKE_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { *out = nullptr; return SPIKE_ERR_HIP; }
+    *out = new spike_handle_s();
+    return SPIKE_OK;
+}
+
+extern "C" int spike_reset(spike_handle h)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    (void)hipStreamSynchronize(h->stream);
+    free_factors(h);
+    return SPIKE_OK;
+}
+
+extern "C" int spike_destroy(spike_handle h)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    spike_reset(h);
+    if (h->comm && g_rccl.ok()) g_rccl.CommDestroy(h->comm);
+    for (auto &e : h->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete h;
+    return SPIKE_OK;
+}
+
+extern "C" const char *spike_last_error(spike_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int spike_set_option(spike_handle h, const char *key, const char *val)
+{
+    if (!h || !key || !val) return SPIKE_ERR_ARG;
+    const std::string k(key), v(val);
+    if (k == "partitions") { h->opt_partitions = atoi(val); if (h->opt_partitions < 0) return fail(h, SPIKE_ERR_ARG, "partitions must be >= 0"); }
+    else if (k == "variant") {
+        if (v == "decoupled" || v == "0") h->variant = SPIKE_VARIANT_DECOUPLED;
+        else if (v == "coupled" || v == "truncated" || v == "1") h->variant = SPIKE_VARIANT_COUPLED;
+        else return fail(h, SPIKE_ERR_ARG, "unknown variant '%s'", val);
+    }
+    else if (k == "boost") h->boost_rel = atof(val);
+    else if (k == "keep_band") h->keep_band = atoi(val);
+    else if (k == "profile") h->profile = atoi(val);
+    else return fail(h, SPIKE_ERR_ARG, "unknown option '%s'", key);
+    return SPIKE_OK;
+}
+
+extern "C" int spike_set_stream(spike_handle h, void *s)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    h->stream = (hipStream_t)s;
+    return SPIKE_OK;
+}
+
+extern "C" int spike_comm_unique_id(char id[SPIKE_UNIQUE_ID_BYTES])
+{
+    if (!id) return SPIKE_ERR_ARG;
+    if (!rccl_load()) return SPIKE_ERR_COMM;
+    ncclUniqueId_ u;
+    if (g_rccl.GetUniqueId(&u) != 0) return SPIKE_ERR_COMM;
+    memcpy(id, u.internal, SPIKE_UNIQUE_ID_BYTES);
+    return SPIKE_OK;
+}
+
+extern "C" int spike_comm_init(spike_handle h, int nranks, int rank, const char id[SPIKE_UNIQUE_ID_BYTES])
+{
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks) return SPIKE_ERR_ARG;
+    if (h->ready) return fail(h, SPIKE_ERR_STATE, "spike_comm_init must precede setup");
+    h->nranks = nranks;
+    h->rank = rank;
+    if (nranks == 1) return SPIKE_OK;
+    if (!id) return SPIKE_ERR_ARG;
+    if (!rccl_load()) return fail(h, SPIKE_ERR_COMM, "cannot load librccl: %s", dlerror());
+    ncclUniqueId_ u;
+    memcpy(u.internal, id, SPIKE_UNIQUE_ID_BYTES);
+    NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    return SPIKE_OK;
+}
+
+// ---- partitioning ------------------------------------------------------------------------------------
+static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
+{
+    const int64_t nblk = (n + BLK - 1) / BLK;
+    int64_t minrows = (int64_t)8 * K;
+    if (minrows < 256) minrows = 256;
+    int64_t target = (int64_t)(2048 / cfg.NW) * cfg.CPW();  // ~8 waves on each of 256 CUs
+    int64_t byrows = n / minrows;
+    int64_t P = target < byrows ? target : byrows;
+    if (P > nblk) P = nblk;
+    if (P < 1) P = 1;
+    return (int)P;
+}
+
+static int build_chains(spike_handle h)
+{
+    const int64_t n = h->n;
+    const int P = h->P;
+    const int R = h->cfg.R, CPW = h->cfg.CPW();
+    const int64_t nblk = (n + BLK - 1) / BLK;
+    if (nblk < P) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", P, P, (long long)nblk);
+    h->chains.resize(P);
+    for (int p = 0; p < P; ++p) {
+        int64_t r0 = (nblk * (int64_t)p) / P * BLK, r1 = (nblk * (int64_t)(p + 1)) / P * BLK;
+        if (r1 > n || p == P - 1) r1 = n;
+        if (r0 > n) r0 = n;
+        const int64_t rows = r1 - r0;
+        if (rows < (h->K > 1 ? h->K : 1)) return fail(h, SPIKE_ERR_PARTITION, "partition %d has %lld rows < K=%d", p, (long long)rows, h->K);
+        h->chains[p].row0 = r0;
+        h->chains[p].nrows = (int32_t)rows;
+        h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
+    }
+    const int ng = (P + CPW - 1) / CPW;
+    h->groups.resize(ng);
+    int64_t t0 = 0, ms = 0;
+    for (int q = 0; q < ng; ++q) {
+        int mx = 0;
+        for (int c = 0; c < CPW && q * CPW + c < P; ++c) mx = std::max(mx, (int)h->chains[q * CPW + c].nsteps);
+        h->groups[q].tile0 = t0;
+        h->groups[q].maxsteps = mx;
+        h->groups[q].pad = 0;
+        t0 += mx;
+        ms = std::max<int64_t>(ms, mx);
+    }
+    h->ntiles = t0;
+    h->maxsteps = ms;
+    return SPIKE_OK;
+}
+
+// one forward+backward pass over all chains: out = blockdiag(A_p)^{-1} (in - corrections)
+static int run_pass(spike_handle h, const double *in, double *out, bool with_corr)
+{
+    SweepArgs a;
+    a.groups = h->dGroups; a.chains = h->dChains; a.nchains = h->P; a.K = h->K;
+    a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
+    a.corr_top = with_corr ? h->dCorrTop : nullptr;
+    a.corr_bot = with_corr ? h->dCorrBot : nullptr;
+    const int ng = (int)h->groups.size();
+    const bool prof = h->profile != 0;
+    auto rec = [&](bool start) {
+        if (!prof) return;
+        if (h->nev >= (int)h->evs.size()) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            h->evs.push_back({e0, e1});
+        }
+        if (start) (void)hipEventRecord(h->evs[h->nev].first, h->stream);
+        else { (void)hipEventRecord(h->evs[h->nev].second, h->stream); ++h->nev; }
+    };
+    rec(true);
+    HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream));
+    rec(false);
+    a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
+    rec(true);
+    HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream));
+    rec(false);
+    return SPIKE_OK;
+}
+
+__global__ void k_gather_tips(const double *g, int K, const ChainDesc *chains, int nchains, double *tips, double *send)
+{
+    const int p = blockIdx.x;
+    const ChainDesc cd = chains[p];
+    for (int a = threadIdx.x; a < K; a += blockDim.x) {
+        const double gt = g[cd.row0 + a], gb = g[cd.row0 + cd.nrows - K + a];
+        tips[((int64_t)p * 2) * K + a] = gt;
+        tips[((int64_t)p * 2 + 1) * K + a] = gb;
+        if (send) {
+            if (p == 0) send[a] = gt;
+            if (p == nchains - 1) send[K + a] = gb;
+        }
+    }
+}
+
+__global__ void k_copy_halo(const double *x, int64_t n, int K, double *send)
+{
+    for (int a = threadIdx.x; a < K; a += blockDim.x) {
+        send[a] = x[a];              // my first K entries (the previous rank's right halo)
+        send[K + a] = x[n - K + a];  // my last K entries  (the next rank's left halo)
+    }
+}
+
+__global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv, int rank, int nranks, double *xh)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) xh[K + i] = x[i];
+    if (i < K) {
+        xh[i] = (rank > 0) ? recv[((int64_t)(rank - 1) * 2 + 1) * K + i] : 0.0;
+        xh[K + n + i] = (rank < nranks - 1) ? recv[((int64_t)(rank + 1) * 2) * K + i] : 0.0;
+    }
+}
+
+// ---- setup -----------------------------------------------------------------------------------------------
+static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
+                      int on_device)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    if (n <= 0 || n_global < n || row0 < 0 || row0 + n > n_global || K < 0 || !band || ld < n)
+        return fail(h, SPIKE_ERR_ARG, "bad sizes n_global=%lld row0=%lld n=%lld K=%d ld=%lld", (long long)n_global, (long long)row0, (long long)n, K, (long long)ld);
+    if (h->nranks == 1 && (row0 != 0 || n != n_global)) return fail(h, SPIKE_ERR_ARG, "single rank must own all rows");
+    if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "n_local too large");
+    SweepCfg cfg;
+    if (!pick_cfg(K, &cfg)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..256)", K);
+    (void)hipStreamSynchronize(h->stream);
+    free_factors(h);
+    const auto t_start = std::chrono::steady_clock::now();
+    h->cfg = cfg;
+    h->n_global = n_global; h->row0 = row0; h->n = n; h->K = K;
+    h->P = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n);
+    int rc = build_chains(h);
+    if (rc) return rc;
+    const int P = h->P;
+    const int nd = 2 * K + 1;
+    hipStream_t st = h->stream;
+
+    // band on device (kept for the coupling blocks, the tips and the Krylov matvec)
+    if (on_device && !h->keep_band) { h->dA = const_cast<double *>(band); h->ownA = false; h->ldA = ld; }
+    else {
+        HIPCHK(dalloc(&h->dA, (size_t)nd * n));
+        h->ownA = true; h->ldA = n;
+        HIPCHK(hipMemcpy2DAsync(h->dA, n * sizeof(double), band, ld * sizeof(double), n * sizeof(double), nd,
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(dalloc(&h->dChains, (size_t)P));
+    HIPCHK(dalloc(&h->dGroups, h->groups.size()));
+    HIPCHK(hipMemcpyAsync(h->dChains, h->chains.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), hipMemcpyHostToDevice, st));
+
+    // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
+    double *dScal = nullptr;
+    HIPCHK(dalloc(&dScal, 2));
+    HIPCHK(launch_absmax_diag(h->dA, h->ldA, K, n, dScal, st));
+    if (h->nranks > 1) NCCLCHK(g_rccl.AllReduce(dScal, dScal, 1, NCCL_FLOAT64, NCCL_MAX, h->comm, st));
+    double dmax = 0.0;
+    HIPCHK(hipMemcpyAsync(&dmax, dScal, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double boost = h->boost_rel * dmax;
+
+    // LU (scratch copy), then pack into sweep tiles
+    double *dLU = nullptr;
+    HIPCHK(dalloc(&dLU, (size_t)nd * n));
+    HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
+    unsigned long long *dNb = (unsigned long long *)(dScal + 1);
+    HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
+    HIPCHK(launch_factor(dLU, n, K, h->dChains, P, boost, dNb, st));
+    const size_t tile_total = (size_t)h->ntiles * (size_t)cfg.tile_doubles();
+    HIPCHK(dalloc(&h->dLt, tile_total));
+    HIPCHK(dalloc(&h->dUt, tile_total));
+    HIPCHK(dalloc(&h->dDinv, (size_t)n));
+    HIPCHK(dalloc(&h->dY, (size_t)n));
+    HIPCHK(dalloc(&h->dTmp, (size_t)n));
+    HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
+    HIPCHK(launch_pack(cfg, dLU, n, K, h->dChains, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
+    unsigned long long nb = 0;
+    HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->nboost = (int64_t)nb;
+    HIPCHK(hipFree(dLU));
+    HIPCHK(hipFree(dScal));
+
+    // ---- spike tips, coupling blocks, interface systems --------------------------------------------
+    const bool multi = h->nranks > 1;
+    const int nif_local = P - 1;
+    const int nif = (K > 0) ? nif_local + (multi && h->rank > 0 ? 1 : 0) + (multi && h->rank < h->nranks - 1 ? 1 : 0) : 0;
+    h->nif = nif;
+    const size_t kk = (size_t)K * K;
+    if (K > 0) {
+        HIPCHK(dalloc(&h->dCorrTop, (size_t)P * K));
+        HIPCHK(dalloc(&h->dCorrBot, (size_t)P * K));
+        HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
+        HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
+        HIPCHK(dalloc(&h->dTips, (size_t)P * 2 * K));
+    }
+    if (nif > 0) {
+        HIPCHK(dalloc(&h->dWt, (size_t)P * kk));
+        HIPCHK(dalloc(&h->dVb, (size_t)P * kk));
+        HIPCHK(dalloc(&h->dBT, (size_t)P * kk));
+        HIPCHK(dalloc(&h->dCT, (size_t)P * kk));
+        HIPCHK(hipMemsetAsync(h->dWt, 0, sizeof(double) * P * kk, st));
+        HIPCHK(hipMemsetAsync(h->dVb, 0, sizeof(double) * P * kk, st));
+        double *rhs = h->dTmp;
+        double *sol = nullptr;
+        HIPCHK(dalloc(&sol, (size_t)n));
+        const bool keep_prof = h->profile;
+        h->profile = 0;
+        for (int which = 0; which < 2; ++which) {
+            HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
+            for (int col = 0; col < K; ++col) {
+                HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
+                rc = run_pass(h, rhs, sol, false);
+                if (rc) return rc;
+                HIPCHK(launch_tip_gather(sol, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st));
+            }
+        }
+        h->profile = keep_prof;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(sol));
+        HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 0, h->dCT, st));
+        HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 1, h->dBT, st));
+
+        // interface i (local numbering): upper chain = i, lower chain = i+1; rank boundaries appended
+        std::vector<double *> Wsrc(nif), Vsrc(nif);
+        double *dWif = nullptr, *dVif = nullptr, *dWork = nullptr;
+        int *dFlag = nullptr;
+        HIPCHK(dalloc(&dWif, (size_t)nif * kk));
+        HIPCHK(dalloc(&dVif, (size_t)nif * kk));
+        HIPCHK(dalloc(&dWork, (size_t)nif * 2 * kk));
+        HIPCHK(dalloc(&dFlag, (size_t)nif));
+        HIPCHK(hipMemsetAsync(dFlag, 0, sizeof(int) * nif, st));
+        HIPCHK(dalloc(&h->dWT, (size_t)nif * kk));
+        HIPCHK(dalloc(&h->dVT, (size_t)nif * kk));
+        HIPCHK(dalloc(&h->dST, (size_t)nif * kk));
+        // local interfaces: W of chain i+1, V of chain i
+        if (nif_local > 0) {
+            HIPCHK(hipMemcpyAsync(dWif, h->dWt + kk, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(dVif, h->dVb, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
+        }
+        int ib_prev = -1, ib_next = -1;
+        if (multi) {
+            // exchange [W_first | V_last] of every rank
+            HIPCHK(dalloc(&h->dSend, 2 * kk > (size_t)2 * K ? 2 * kk : (size_t)2 * K));
+            HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * (2 * kk > (size_t)2 * K ? 2 * kk : (size_t)2 * K)));
+            HIPCHK(hipMemcpyAsync(h->dSend, h->dWt, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->dSend + kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+            NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, 2 * kk, NCCL_FLOAT64, h->comm, st));
+            int idx = nif_local;
+            if (h->rank > 0) {  // interface with the previous rank: V = prev rank's V_last, W = my W_first
+                ib_prev = idx++;
+                HIPCHK(hipMemcpyAsync(dWif + (size_t)ib_prev * kk, h->dWt, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(dVif + (size_t)ib_prev * kk, h->dRecv + (size_t)(h->rank - 1) * 2 * kk + kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+            }
+            if (h->rank < h->nranks - 1) {  // interface with the next rank: V = my V_last, W = next rank's W_first
+                ib_next = idx++;
+                HIPCHK(hipMemcpyAsync(dWif + (size_t)ib_next * kk, h->dRecv + (size_t)(h->rank + 1) * 2 * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(dVif + (size_t)ib_next * kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        HIPCHK(launch_iface_setup(K, nif, dWif, dVif, h->dWT, h->dVT, h->dST, dWork, dFlag, st));
+        std::vector<int> flags(nif, 0);
+        HIPCHK(hipMemcpyAsync(flags.data(), dFlag, sizeof(int) * nif, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(dWif)); HIPCHK(hipFree(dVif)); HIPCHK(hipFree(dWork)); HIPCHK(hipFree(dFlag));
+        for (int i = 0; i < nif; ++i)
+            if (flags[i]) return fail(h, SPIKE_ERR_SINGULAR, "interface system %d is singular", i);
+
+        std::vector<IfaceDesc> ifs(nif);
+        for (int i = 0; i < nif_local; ++i) {
+            IfaceDesc &d = ifs[i];
+            d.gb = h->dTips + ((size_t)i * 2 + 1) * K;
+            d.gt = h->dTips + ((size_t)(i + 1) * 2) * K;
+            d.WT = h->dWT + (size_t)i * kk; d.ST = h->dST + (size_t)i * kk; d.VT = h->dVT + (size_t)i * kk;
+            d.BT = h->dBT + (size_t)i * kk; d.CT = h->dCT + (size_t)(i + 1) * kk;
+            d.corr_bot = h->dCorrBot + (size_t)i * K;
+            d.corr_top = h->dCorrTop + (size_t)(i + 1) * K;
+        }
+        if (ib_prev >= 0) {
+            IfaceDesc &d = ifs[ib_prev];
+            d.gb = h->dRecv + ((size_t)(h->rank - 1) * 2 + 1) * K;  // previous rank's gb_last (apply-time layout: 2K per rank)
+            d.gt = h->dTips;
+            d.WT = h->dWT + (size_t)ib_prev * kk; d.ST = h->dST + (size_t)ib_prev * kk; d.VT = h->dVT + (size_t)ib_prev * kk;
+            d.BT = nullptr; d.CT = h->dCT;
+            d.corr_bot = nullptr; d.corr_top = h->dCorrTop;
+        }
+        if (ib_next >= 0) {
+            IfaceDesc &d = ifs[ib_next];
+            d.gb = h->dTips + ((size_t)(P - 1) * 2 + 1) * K;
+            d.gt = h->dRecv + ((size_t)(h->rank + 1) * 2) * K;  // next rank's gt_first
+            d.WT = h->dWT + (size_t)ib_next * kk; d.ST = h->dST + (size_t)ib_next * kk; d.VT = h->dVT + (size_t)ib_next * kk;
+            d.BT = h->dBT + (size_t)(P - 1) * kk; d.CT = nullptr;
+            d.corr_bot = h->dCorrBot + (size_t)(P - 1) * K; d.corr_top = nullptr;
+        }
+        HIPCHK(dalloc(&h->dIfs, (size_t)nif));
+        HIPCHK(hipMemcpyAsync(h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    if (multi && !h->dSend) {
+        HIPCHK(dalloc(&h->dSend, (size_t)2 * (K > 0 ? K : 1)));
+        HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * 2 * (K > 0 ? K : 1)));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    h->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    h->ready = true;
+    return SPIKE_OK;
+}
+
+extern "C" int spike_setup_band(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, int K,
+                                const double *band, int64_t ld, int on_device)
+{
+    return setup_impl(h, n_global, row0, n_local, K, band, ld, on_device);
+}
+
+// ---- apply ---------------------------------------------------------------------------------------------------
+static int apply_dev(spike_handle h, const double *x, double *y)
+{
+    hipStream_t st = h->stream;
+    h->nev = 0;
+    int rc = run_pass(h, x, y, false);
+    if (rc) return rc;
+    if (h->variant == SPIKE_VARIANT_COUPLED && h->nif > 0) {
+        const bool multi = h->nranks > 1;
+        hipLaunchKernelGGL(k_gather_tips, dim3(h->P), dim3(64), 0, st, y, h->K, h->dChains, h->P, h->dTips, multi ? h->dSend : nullptr);
+        HIPCHK(hipGetLastError());
+        if (multi) NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, (size_t)2 * h->K, NCCL_FLOAT64, h->comm, st));
+        HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfs, st));
+        rc = run_pass(h, x, y, true);
+        if (rc) return rc;
+    }
+    return SPIKE_OK;
+}
+
+extern "C" int spike_apply(spike_handle h, const double *x, double *y, int on_device)
+{
+    if (!h || !x || !y || x == y) return fail(h, SPIKE_ERR_ARG, "spike_apply: bad pointers (x must differ from y)");
+    if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_apply before setup");
+    if (on_device) return apply_dev(h, x, y);
+    double *dx = nullptr, *dy = nullptr;
+    HIPCHK(dalloc(&dx, (size_t)h->n));
+    HIPCHK(dalloc(&dy, (size_t)h->n));
+    HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    int rc = apply_dev(h, dx, dy);
+    if (rc == SPIKE_OK) {
+        hipError_t e = hipMemcpyAsync(y, dy, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, SPIKE_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
+    return rc;
+}
+
+extern "C" int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches)
+{
+    if (!h || !ms_total || !nlaunches) return SPIKE_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (int i = 0; i < h->nev; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->evs[i].first, h->evs[i].second));
+        tot += ms;
+    }
+    *ms_total = tot;
+    *nlaunches = h->nev;
+    return SPIKE_OK;
+}
+
+// ---- matvec with the kept band ---------------------------------------------------------------------------
+static int matvec_dev(spike_handle h, const double *x, double *y)
+{
+    hipStream_t st = h->stream;
+    const int K = h->K;
+    if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
+    const bool multi = h->nranks > 1;
+    if (multi && K > 0) {
+        hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, x, h->n, K, h->dSend);
+        NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, (size_t)2 * K, NCCL_FLOAT64, h->comm, st));
+    }
+    hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh);
+    HIPCHK(hipGetLastError());
+    HIPCHK(launch_band_matvec(h->n_global, h->row0, h->n, K, h->dA, h->ldA, h->dXh, y, st));
+    return SPIKE_OK;
+}
+
+extern "C" int spike_band_matvec(spike_handle h, const double *x, double *y)
+{
+    if (!h || !x || !y) return SPIKE_ERR_ARG;
+    if (!h->ready || !h->dA) return fail(h, SPIKE_ERR_STATE, "spike_band_matvec needs a setup with the band kept");
+    return matvec_dev(h, x, y);
+}
+
+extern "C" int spike_gen_band(void *stream, int64_t n_global, int K, uint64_t seed, double delta, int64_t row0,
+                              int64_t nrows, double *band, int64_t ld)
+{
+    if (!band || K < 0 || nrows < 0 || ld < nrows) return SPIKE_ERR_ARG;
+    hipError_t e = launch_gen_band(n_global, K, seed, delta, row0, nrows, band, ld, (hipStream_t)stream);
+    return e == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
+}
+
+// ---- GMRES -----------------------------------------------------------------------------------------------------
+static int dist_sum(spike_handle h, double *dvals, int count)
+{
+    if (h->nranks > 1) NCCLCHK(g_rccl.AllReduce(dvals, dvals, (size_t)count, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream));
+    return SPIKE_OK;
+}
+
+extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int restart, double rtol, int maxit, int use_pc,
+                           int *iters, double *rnorm, double *solve_ms)
+{
+    if (!h || !b || !x || restart < 1 || maxit < 0) return SPIKE_ERR_ARG;
+    if (!h->ready || !h->dA) return fail(h, SPIKE_ERR_STATE, "spike_gmres needs a setup with the band kept");
+    hipStream_t st = h->stream;
+    const int64_t n = h->n;
+    const int m = restart;
+    if (h->gm_restart != m) {
+        auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+        F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
+        HIPCHK(dalloc(&h->dV, (size_t)(m + 1) * n));
+        HIPCHK(dalloc(&h->dW, (size_t)n));
+        HIPCHK(dalloc(&h->dZ, (size_t)n));
+        HIPCHK(dalloc(&h->dDots, (size_t)m + 2));
+        HIPCHK(dalloc(&h->dCoef, (size_t)m + 2));
+        h->gm_restart = m;
+    }
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m), hcol(m + 2);
+    int it = 0, rc = 0;
+    bool conv = false;
+    double r0 = -1.0, rn = 0.0;
+    HIPCHK(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    auto precond = [&](const double *in, double *out) -> int {
+        if (use_pc) return apply_dev(h, in, out);
+        HIPCHK(hipMemcpyAsync(out, in, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+        return SPIKE_OK;
+    };
+    while (it < maxit && !conv) {
+        if ((rc = matvec_dev(h, x, h->dW))) return rc;
+        HIPCHK(launch_residual(b, h->dW, h->dW, n, st));
+        if ((rc = precond(h->dW, h->dZ))) return rc;
+        HIPCHK(launch_dots(h->dZ, n, 1, h->dZ, n, h->dDots, st));
+        if ((rc = dist_sum(h, h->dDots, 1))) return rc;
+        double bb = 0.0;
+        HIPCHK(hipMemcpyAsync(&bb, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double beta = std::sqrt(bb);
+        if (r0 < 0.0) r0 = beta;
+        rn = beta;
+        if (beta <= rtol * r0 || beta == 0.0) { conv = true; break; }
+        HIPCHK(launch_scale_copy(h->dZ, h->dDots, 1, h->dV, n, st));  // v0 = z / sqrt(dots[0])
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int j = 0;
+        for (j = 0; j < m && it < maxit; ++j) {
+            double *vj = h->dV + (size_t)j * n, *vn = h->dV + (size_t)(j + 1) * n;
+            if ((rc = matvec_dev(h, vj, h->dW))) return rc;
+            if ((rc = precond(h->dW, vn))) return rc;
+            // classical Gram-Schmidt with one re-orthogonalisation (two fused passes instead of j+1 dots)
+            for (int i = 0; i <= j; ++i) hcol[i] = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                HIPCHK(launch_dots(h->dV, n, j + 1, vn, n, h->dDots, st));
+                if ((rc = dist_sum(h, h->dDots, j + 1))) return rc;
+                HIPCHK(launch_axpys(h->dV, n, j + 1, h->dDots, vn, n, -1.0, st));
+                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 1), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int i = 0; i <= j; ++i) hcol[i] += yv[i];
+            }
+            HIPCHK(launch_dots(vn, n, 1, vn, n, h->dDots, st));
+            if ((rc = dist_sum(h, h->dDots, 1))) return rc;
+            double hh = 0.0;
+            HIPCHK(hipMemcpyAsync(&hh, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const double hn = std::sqrt(hh);
+            if (hn != 0.0) HIPCHK(launch_scale_copy(vn, h->dDots, 1, vn, n, st));
+            for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
+            H[(size_t)(j + 1) * m + j] = hn;
+            for (int i = 0; i < j; ++i) {
+                const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)i * m + j] = t;
+            }
+            const double a0 = H[(size_t)j * m + j], a1 = H[(size_t)(j + 1) * m + j];
+            const double den = std::sqrt(a0 * a0 + a1 * a1);
+            cs[j] = den == 0.0 ? 1.0 : a0 / den;
+            sn[j] = den == 0.0 ? 0.0 : a1 / den;
+            H[(size_t)j * m + j] = cs[j] * a0 + sn[j] * a1;
+            H[(size_t)(j + 1) * m + j] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            ++it;
+            rn = std::fabs(g[j + 1]);
+            if (rn <= rtol * r0) { conv = true; ++j; break; }
+        }
+        const int jj = j;
+        for (int i = jj - 1; i >= 0; --i) {
+            double t = g[i];
+            for (int c = i + 1; c < jj; ++c) t -= H[(size_t)i * m + c] * yv[c];
+            yv[i] = t / H[(size_t)i * m + i];
+        }
+        HIPCHK(hipMemcpyAsync(h->dCoef, yv.data(), sizeof(double) * jj, hipMemcpyHostToDevice, st));
+        HIPCHK(launch_lincomb(h->dV, n, jj, h->dCoef, x, n, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (solve_ms) *solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (iters) *iters = it;
+    if (rnorm) *rnorm = rn;
+    return conv ? 0 : 1;
+}
+
+// ---- CSR entry: band extraction (reference src/matbanded.c:22-107) then setup ----------------------------
+extern "C" int spike_csr_extract_setup(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja,
+                                       const double *a, int kmax, double frac, int *k_out, double *frac_out);
+
+extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
+                               int kmax, double frac, int *k_out, double *frac_out)
+{
+    return spike_csr_extract_setup(h, n, ia, ja, a, kmax, frac, k_out, frac_out);
+}
+
+// ---- introspection ---------------------------------------------------------------------------------------------
+extern "C" int spike_get_info(spike_handle h, spike_info *o)
+{
+    if (!h || !o) return SPIKE_ERR_ARG;
+    memset(o, 0, sizeof *o);
+    o->n_local = h->n; o->n_global = h->n_global; o->row0 = h->row0; o->K = h->K; o->Kp = h->cfg.KP();
+    o->P_local = h->P; o->P_global = h->P * h->nranks; o->variant = h->variant;
+    o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
+    o->nboost = h->nboost;
+    o->factor_bytes = (int64_t)(2 * (size_t)h->ntiles * (size_t)h->cfg.tile_doubles() + (size_t)h->n) * 8;
+    o->iface_bytes = (int64_t)h->nif * 5 * (int64_t)h->K * h->K * 8;
+    o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
+    return SPIKE_OK;
+}
+
+extern "C" int spike_view(spike_handle h, char *buf, size_t len)
+{
+    if (!h || !buf || !len) return SPIKE_ERR_ARG;
+    snprintf(buf, len,
+             "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
+             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d\n",
+             (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P,
+             h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
+             (long long)h->nboost, h->setup_ms, h->nranks);
+    return SPIKE_OK;
+}
+
+extern "C" int spike_get_tips(spike_handle h, double *Vb, double *Wt)
+{
+    if (!h || !Vb || !Wt) return SPIKE_ERR_ARG;
+    if (!h->ready) return fail(h, SPIKE_ERR_STATE, "no factors");
+    const size_t kk = (size_t)h->K * h->K;
+    if (h->P < 2 || kk == 0 || !h->dVb) return SPIKE_OK;
+    // interface i: V of chain i, W of chain i+1
+    HIPCHK(hipMemcpy(Vb, h->dVb, sizeof(double) * (h->P - 1) * kk, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Wt, h->dWt + kk, sizeof(double) * (h->P - 1) * kk, hipMemcpyDeviceToHost));
+    return SPIKE_OK;
+}
+
+extern "C" int spike_set_extracted(spike_handle h, int k, double frac)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    h->k_extracted = k;
+    h->frac_extracted = frac;
+    return SPIKE_OK;
+}

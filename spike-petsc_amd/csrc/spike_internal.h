@@ -1,0 +1,101 @@
+// spike_internal.h -- shared declarations between the HIP kernels and the C-ABI engine.
+// gfx950 only.  Not part of the public interface (see include/spike_mi355.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spike {
+
+constexpr int BLK = 64;  // partition boundaries fall on multiples of 64 rows
+
+// One SPIKE partition = one chain of row blocks swept sequentially.
+struct ChainDesc {
+    int64_t row0;    // first local row
+    int32_t nrows;   // rows in the partition
+    int32_t nsteps;  // ceil(nrows / R)
+};
+
+// One workgroup = NW waves sweeping CPW = 64/R chains in lock-step.
+struct GroupDesc {
+    int64_t tile0;     // index of the group's first tile (tiles of a group are consecutive steps)
+    int32_t maxsteps;  // max nsteps over the group's chains
+    int32_t pad;
+};
+
+// Kernel configuration picked from the half-bandwidth.
+struct SweepCfg {
+    int R;    // rows per block (8,16,32,64)
+    int DPW;  // diagonals per wave (= tile entries per lane per wave)
+    int NW;   // waves per chain
+    int KP() const { return DPW * NW; }
+    int CPW() const { return 64 / R; }
+    int64_t tile_doubles() const { return (int64_t)NW * DPW * 64; }
+};
+
+struct SweepArgs {
+    const double *tiles;
+    const GroupDesc *groups;
+    const ChainDesc *chains;
+    int nchains;
+    const double *in;
+    double *out;
+    const double *dinv;      // forward only
+    const double *corr_top;  // [nchains*K] or null (forward only)
+    const double *corr_bot;  // [nchains*K] or null
+    int K;
+};
+
+// One reduced (interface) system between partition "lo" and the partition below it.
+struct IfaceDesc {
+    const double *gb;  // K doubles: bottom tip of g of the upper partition
+    const double *gt;  // K doubles: top tip of g of the lower partition
+    const double *WT;  // K*K, column-major W^(t)   (WT[c*K+a] = W[a][c])
+    const double *ST;  // K*K, column-major (I - W V)^{-1}
+    const double *VT;  // K*K, column-major V^(b)
+    const double *BT;  // K*K, column-major B (coupling block of the upper partition) or null
+    const double *CT;  // K*K, column-major C (coupling block of the lower partition) or null
+    double *corr_bot;  // K doubles: B * x^(t)   (for the upper partition) or null
+    double *corr_top;  // K doubles: C * x^(b)   (for the lower partition) or null
+};
+
+bool pick_cfg(int K, SweepCfg *cfg);
+
+// launchers (spike_kernels.hip)
+hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st);
+hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+                         unsigned long long *nboost, hipStream_t st);
+hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
+                       const GroupDesc *groups, int nchains, int64_t total_blocks, const int64_t *blk_prefix,
+                       double *Lt, double *Ut, double *dinv, hipStream_t st);
+hipError_t launch_absmax_diag(const double *band, int64_t ld, int K, int64_t n, double *out, hipStream_t st);
+hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
+                           int64_t ld, hipStream_t st);
+hipError_t launch_band_matvec(int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
+                              const double *xh, double *y, hipStream_t st);
+// tips: rhs[row0+a] = block(a,b) for every chain (which: 0 = C at top rows of chains with has_top,
+// 1 = B at bottom rows of chains with has_bot); gather copies K rows of sol into column b of out.
+hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st);
+hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, int nchains, int which, int col,
+                             double *out, hipStream_t st);
+// coupling blocks B (which=1) / C (which=0) of every chain as dense column-major K x K
+hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                                  const ChainDesc *chains, int nchains, int which, double *out, hipStream_t st);
+// S = I - W V, inverse by Gauss-Jordan with partial pivoting; W,V row-major K x K per interface in;
+// outputs column-major WT, VT, ST.  flag[i] != 0 when interface i is singular.
+hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
+                              double *work, int *flag, hipStream_t st);
+hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st);
+
+// Krylov pieces (spike_krylov.hip)
+hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out /*nvec*/,
+                       hipStream_t st);
+hipError_t launch_axpys(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,
+                        hipStream_t st);
+hipError_t launch_scale_copy(const double *w, const double *scal_dev, int invert, double *out, int64_t n,
+                             hipStream_t st);
+hipError_t launch_residual(const double *b, const double *ax, double *r, int64_t n, hipStream_t st);
+hipError_t launch_lincomb(const double *V, int64_t ldv, int nvec, const double *y_dev, double *x, int64_t n,
+                          hipStream_t st);
+
+}  // namespace spike

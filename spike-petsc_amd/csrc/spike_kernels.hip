@@ -1,0 +1,667 @@
+// spike_kernels.hip -- hand-written gfx950 kernels of the SPIKE banded preconditioner.
+//
+// Reference slot filled: the inner PC of PCBANDED, /root/reference/src/matbanded.c:176-178
+// (PCSetUp(b->pc): k_factor, k_pack, tips, k_iface_setup) and :190 (PCApply(b->pc,x,y):
+// k_sweep forward/backward, k_iface_apply).  The reference holds no device code at all;
+// everything here is new (DESIGN.md gives the data layout and the roofline of each kernel).
+//
+// Design notes for CDNA4:
+//  * wave = 64 lanes.  In the sweeps a lane owns ONE ROW of a row block, a wave owns DPW
+//    diagonals of the band, NW waves make up the KP = DPW*NW streamed diagonals of a chain.
+//  * the packed factors ("tiles") are stored in exactly the order the lanes consume them:
+//    every tile load is one 16-byte-per-lane, 1-KiB-per-wave contiguous request, and a chain
+//    streams one contiguous region of HBM front to back.  Each factor byte is read once.
+//  * the triangular recurrence inside a row block is removed at pack time: the R x R diagonal
+//    blocks of L and of D^{-1}U are stored INVERTED, so a block step is two dependent
+//    matrix-vector products (far part, near part) with no serial substitution.
+//  * the right-hand-side window lives in LDS (2-3 KiB); band data never touches LDS: it is
+//    used once, straight from VGPRs, with the next step's tile already in flight.
+#include "spike_internal.h"
+
+namespace spike {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// configuration
+// ------------------------------------------------------------------------------------------
+bool pick_cfg(int K, SweepCfg *cfg)
+{
+    if (K < 0 || K > 256) return false;
+    if (K <= 8) *cfg = {8, 8, 1};
+    else if (K <= 16) *cfg = {16, 16, 1};
+    else if (K <= 32) *cfg = {32, 32, 1};
+    else { int nw = (K + 31) / 32; if (nw == 5) nw = 6; if (nw == 7) nw = 8; *cfg = {64, 32, nw}; }
+    return true;
+}
+
+__host__ __device__ inline constexpr int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// element index (in doubles) of entry (lane, d) inside one tile; d in [1, KP]
+__device__ __forceinline__ int64_t tile_elem(int DPW, int lane, int d)
+{
+    const int w = (d - 1) / DPW, dd = (d - 1) % DPW;
+    return ((int64_t)(w * (DPW >> 1) + (dd >> 1)) * 64 + lane) * 2 + (dd & 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep: one triangular sweep (forward with L, or backward with D^{-1}U) of every chain.
+//   forward : out = D^{-1} L^{-1} (in - corrections)
+//   backward: out = (D^{-1}U)^{-1} in
+// Bound: HBM.  Algorithmic bytes per row: KP*8 (tile) + 8 (in) + 8 (out) [+8 dinv forward].
+// ------------------------------------------------------------------------------------------
+template <int R, int DPW, int NW, bool REV>
+__global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
+{
+    constexpr int CPW = 64 / R;
+    constexpr int KP = DPW * NW;
+    constexpr int NLD = DPW / 2;
+    constexpr int WS = next_pow2(KP + R);
+    constexpr int NWB = ((R - 2) / DPW + 1) < NW ? ((R - 2) / DPW + 1) : NW;  // waves that own in-block entries
+    constexpr int64_t TILE2 = (int64_t)NW * NLD * 64;                         // tile size in double2
+
+    __shared__ double W[CPW][WS];       // circular window of finished values, per chain
+    __shared__ double W2[CPW][KP + R];  // [KP zeros][R block-local intermediates]
+    __shared__ double red[NW][64];
+    __shared__ double red2[NWB][64];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane / R, lr = lane % R;
+    const int p = blockIdx.x * CPW + c;
+    const bool valid = p < a.nchains;
+    ChainDesc cd;
+    cd.row0 = 0; cd.nrows = 0; cd.nsteps = 0;
+    if (valid) cd = a.chains[p];
+    const GroupDesc gd = a.groups[blockIdx.x];
+
+    for (int t = threadIdx.x; t < CPW * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
+    for (int t = threadIdx.x; t < CPW * (KP + R); t += NW * 64) (&W2[0][0])[t] = 0.0;
+    __syncthreads();
+
+    const d2 *tp = reinterpret_cast<const d2 *>(a.tiles) + gd.tile0 * TILE2 + (int64_t)(w * NLD) * 64 + lane;
+    const int K = a.K;
+    const double *ctop = a.corr_top, *cbot = a.corr_bot;
+
+    d2 tA[NLD], tB[NLD];
+    int pos = 0;
+
+    auto load_tile = [&](d2(&t)[NLD], int s) {
+        const d2 *q = tp + (int64_t)s * TILE2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) t[i] = __builtin_nontemporal_load(q + i * 64);
+    };
+
+    auto step = [&](const d2(&t)[NLD], int s) {
+        const bool actc = valid && s < cd.nsteps;
+        const int rl = REV ? (cd.nsteps * R - 1 - (s * R + lr)) : (s * R + lr);
+        const bool act = actc && rl < cd.nrows;
+        const int64_t gi = cd.row0 + rl;
+        double fv = act ? a.in[gi] : 0.0;
+        double dv = 1.0;
+        if (!REV) {
+            if (act) dv = a.dinv[gi];
+            if (ctop != nullptr && act) {
+                if (rl < K) fv -= ctop[(int64_t)p * K + rl];
+                if (rl >= cd.nrows - K) fv -= cbot[(int64_t)p * K + (rl - (cd.nrows - K))];
+            }
+        }
+        // ---- phase A: far part (columns of earlier blocks).  The block's own window slots are
+        // zero while it runs, so in-block entries (stored in the same tile) contribute nothing.
+        W[c][(pos + lr) & (WS - 1)] = 0.0;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int d0 = w * DPW + 1 + 2 * i;
+            acc0 = fma(t[i].x, W[c][(pos + lr - d0) & (WS - 1)], acc0);
+            acc1 = fma(t[i].y, W[c][(pos + lr - d0 - 1) & (WS - 1)], acc1);
+        }
+        double acc = acc0 + acc1;
+        if (NW > 1) {
+            red[w][lane] = acc;
+            __syncthreads();
+            acc = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) acc += red[ww][lane];
+        }
+        const double tt = fv - acc;
+        // ---- phase B: in-block part through the inverted diagonal block (entries stored negated)
+        W2[c][KP + lr] = tt;
+        double g = tt;
+        if (w < NWB) {
+            double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int d0 = w * DPW + 1 + 2 * i;
+                b0 = fma(t[i].x, W2[c][KP + lr - d0], b0);
+                b1 = fma(t[i].y, W2[c][KP + lr - d0 - 1], b1);
+            }
+            if (NW > 1) red2[w][lane] = b0 + b1;
+            else g = tt - (b0 + b1);
+        }
+        if (NW > 1) {
+            __syncthreads();
+            double s2 = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NWB; ++ww) s2 += red2[ww][lane];
+            g = tt - s2;
+        }
+        W[c][(pos + lr) & (WS - 1)] = g;
+        if (act && w == 0) a.out[gi] = REV ? g : g * dv;
+        pos += R;
+    };
+
+    const int ns = gd.maxsteps;
+    if (ns > 0) load_tile(tA, 0);
+    for (int s = 0; s < ns; s += 2) {
+        if (s + 1 < ns) load_tile(tB, s + 1);
+        step(tA, s);
+        if (s + 1 < ns) {
+            if (s + 2 < ns) load_tile(tA, s + 2);
+            step(tB, s + 1);
+        }
+    }
+}
+
+template <int R, int DPW, int NW>
+static hipError_t launch_sweep_t(bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
+{
+    if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true>), dim3(ngroups), dim3(NW * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false>), dim3(ngroups), dim3(NW * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
+{
+    if (ngroups <= 0) return hipSuccess;
+    if (cfg.R == 8) return launch_sweep_t<8, 8, 1>(rev, ngroups, a, st);
+    if (cfg.R == 16) return launch_sweep_t<16, 16, 1>(rev, ngroups, a, st);
+    if (cfg.R == 32) return launch_sweep_t<32, 32, 1>(rev, ngroups, a, st);
+    switch (cfg.NW) {
+    case 2: return launch_sweep_t<64, 32, 2>(rev, ngroups, a, st);
+    case 3: return launch_sweep_t<64, 32, 3>(rev, ngroups, a, st);
+    case 4: return launch_sweep_t<64, 32, 4>(rev, ngroups, a, st);
+    case 6: return launch_sweep_t<64, 32, 6>(rev, ngroups, a, st);
+    case 8: return launch_sweep_t<64, 32, 8>(rev, ngroups, a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_factor: banded LU without pivoting (pivot boosting), in place on the diagonal-major band,
+// one workgroup per partition, right-looking.  Generic-K first version: the (K x K) active
+// window is updated in L2/MALL; the update of one diagonal is a coalesced wave access.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, double boost,
+                                                unsigned long long *nboost)
+{
+    extern __shared__ double sh[];
+    double *u = sh, *l = sh + K;
+    __shared__ double spiv;
+    const ChainDesc cd = chains[blockIdx.x];
+    const int64_t s = cd.row0, e = s + cd.nrows;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long nb = 0;
+    for (int64_t i = s; i < e; ++i) {
+        const int m = (int)((e - 1 - i) < K ? (e - 1 - i) : K);
+        if (tid == 0) {
+            double piv = lu[(int64_t)K * ld + i];
+            if (fabs(piv) < boost) {
+                piv = (piv < 0.0) ? -boost : boost;
+                lu[(int64_t)K * ld + i] = piv;
+                ++nb;
+            }
+            spiv = piv;
+        }
+        for (int t = tid; t < m; t += 256) u[t] = lu[(int64_t)(K + 1 + t) * ld + i];
+        __syncthreads();
+        const double piv = spiv;
+        for (int t = tid; t < m; t += 256) {
+            const int64_t ad = (int64_t)(K - 1 - t) * ld + i + 1 + t;
+            const double lv = lu[ad] / piv;
+            lu[ad] = lv;
+            l[t] = lv;
+        }
+        __syncthreads();
+        for (int delta = -(m - 1) + wave; delta <= m - 1; delta += 4) {
+            const int lo = delta < 0 ? -delta : 0;
+            const int hi = delta > 0 ? m - 1 - delta : m - 1;
+            double *row = lu + (int64_t)(K + delta) * ld + i + 1;
+            for (int tr = lo + lane; tr <= hi; tr += 64) row[tr] -= l[tr] * u[tr + delta];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && nb) atomicAdd(nboost, nb);
+}
+
+hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+                         unsigned long long *nboost, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_factor, dim3(nchains), dim3(256), (size_t)(2 * (K > 0 ? K : 1)) * sizeof(double), st, lu, ld,
+                       K, chains, boost, nboost);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pack: LU band -> sweep tiles.  One wave per (chain, row block): inverts the R x R diagonal
+// blocks of L (unit lower) and of D^{-1}U (unit upper), negates them, and scatters near and
+// far entries into the lane-linear tile order of k_sweep.
+// ------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64) void k_pack(int DPW, int NW, const double *lu, int64_t ld, int K,
+                                             const ChainDesc *chains, const GroupDesc *groups, double *Lt, double *Ut,
+                                             double *dinv)
+{
+    constexpr int CPW = 64 / R;
+    __shared__ double Mb[R * R];
+    __shared__ double X[R * R];
+    const int sb = blockIdx.x, p = blockIdx.y;
+    const ChainDesc cd = chains[p];
+    if (sb >= cd.nsteps) return;
+    const GroupDesc gd = groups[p / CPW];
+    const int c = p % CPW;
+    const int j = threadIdx.x;
+    const int64_t i0 = cd.row0 + (int64_t)sb * R;
+    const int64_t tdbl = (int64_t)NW * DPW * 64;
+    const int rows_here = (cd.nrows - sb * R) < R ? (cd.nrows - sb * R) : R;  // valid rows in this block
+    const int Kn = K < R - 1 ? K : R - 1;
+
+    // ---------------- L ----------------
+    for (int t = j; t < R * R; t += 64) Mb[t] = 0.0;
+    __syncthreads();
+    for (int d = 1; d <= Kn; ++d) {
+        const int r = j;
+        if (r < rows_here && r >= d) Mb[r * R + (r - d)] = lu[(int64_t)(K - d) * ld + i0 + r];
+    }
+    __syncthreads();
+    if (j < R) {
+        for (int r = 0; r < R; ++r) {
+            double acc = (r == j) ? 1.0 : 0.0;
+            for (int cc = 0; cc < r; ++cc) acc -= Mb[r * R + cc] * X[cc * R + j];
+            X[r * R + j] = acc;
+        }
+    }
+    __syncthreads();
+    {
+        double *T = Lt + (gd.tile0 + sb) * tdbl;
+        // near: entry (row r, column j<r) -> d = r-j, stored negated
+        if (j < R)
+            for (int r = j + 1; r < R; ++r) T[tile_elem(DPW, c * R + r, r - j)] = -X[r * R + j];
+        // far: columns before the block, inside the partition
+        const int r = j;
+        if (r < rows_here)
+            for (int d = r + 1; d <= K; ++d)
+                if ((int64_t)sb * R + r - d >= 0) T[tile_elem(DPW, c * R + r, d)] = lu[(int64_t)(K - d) * ld + i0 + r];
+    }
+    __syncthreads();
+    // ---------------- U (unit upper after row scaling by 1/diag) ----------------
+    double di = 1.0;
+    if (j < rows_here) {
+        di = 1.0 / lu[(int64_t)K * ld + i0 + j];
+        dinv[i0 + j] = di;
+    }
+    for (int t = j; t < R * R; t += 64) Mb[t] = 0.0;
+    __syncthreads();
+    for (int d = 1; d <= Kn; ++d) {
+        const int r = j;
+        if (r < rows_here && r + d < rows_here) Mb[r * R + (r + d)] = lu[(int64_t)(K + d) * ld + i0 + r] * di;
+    }
+    __syncthreads();
+    if (j < R) {
+        for (int r = R - 1; r >= 0; --r) {
+            double acc = (r == j) ? 1.0 : 0.0;
+            for (int cc = r + 1; cc < R; ++cc) acc -= Mb[r * R + cc] * X[cc * R + j];
+            X[r * R + j] = acc;
+        }
+    }
+    __syncthreads();
+    {
+        double *T = Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl;
+        if (j < R)
+            for (int r = 0; r < j; ++r) T[tile_elem(DPW, c * R + (R - 1 - r), j - r)] = -X[r * R + j];
+        const int r = j;
+        if (r < rows_here)
+            for (int d = R - r; d <= K; ++d)
+                if ((int64_t)sb * R + r + d < cd.nrows)
+                    T[tile_elem(DPW, c * R + (R - 1 - r), d)] = lu[(int64_t)(K + d) * ld + i0 + r] * di;
+    }
+}
+
+hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
+                       const GroupDesc *groups, int nchains, int64_t maxsteps, const int64_t *, double *Lt, double *Ut,
+                       double *dinv, hipStream_t st)
+{
+    if (nchains <= 0 || maxsteps <= 0) return hipSuccess;
+    dim3 grid((unsigned)maxsteps, (unsigned)nchains);
+    switch (cfg.R) {
+    case 8: hipLaunchKernelGGL((k_pack<8>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    case 16: hipLaunchKernelGGL((k_pack<16>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    case 32: hipLaunchKernelGGL((k_pack<32>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    case 64: hipLaunchKernelGGL((k_pack<64>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// small setup helpers
+// ------------------------------------------------------------------------------------------
+__global__ void k_absmax_diag(const double *band, int64_t ld, int K, int64_t n, unsigned long long *out)
+{
+    double m = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = fabs(band[(int64_t)K * ld + i]);
+        m = v > m ? v : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = __shfl_down(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+hipError_t launch_absmax_diag(const double *band, int64_t ld, int K, int64_t n, double *out, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_absmax_diag, dim3(grid), dim3(256), 0, st, band, ld, K, n, (unsigned long long *)out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// must stay bit-identical to oracle/spike_oracle.c:orc_gen_band (no fp contraction)
+__global__ void k_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
+                           int64_t ld)
+{
+#pragma clang fp contract(off)
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const int nd = 2 * K + 1;
+    const int64_t gi = row0 + i;
+    double s = 0.0;
+    for (int d = 0; d < nd; ++d) {
+        const int64_t c = gi + d - K;
+        double v = 0.0;
+        if (d != K && c >= 0 && c < N) {
+            const uint64_t z = splitmix64(seed ^ ((uint64_t)gi * (uint64_t)nd + (uint64_t)d));
+            v = (double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+            s += fabs(v);
+        }
+        band[(int64_t)d * ld + i] = v;
+    }
+    band[(int64_t)K * ld + i] = delta * s + (s == 0.0 ? 1.0 : 0.0);
+}
+
+hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
+                           int64_t ld, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gen_band, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, N, K, seed, delta, row0,
+                       nrows, band, ld);
+    return hipGetLastError();
+}
+
+// y = A x, rows local, xh = x extended by K halo entries on both sides (xh[K + j] = x[j])
+__global__ void k_band_matvec(int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
+                              const double *xh, double *y)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = row0 + i;
+    int d0 = (gi - K < 0) ? (int)(K - gi) : 0;
+    int d1 = (gi + K >= n_global) ? (int)(n_global - 1 - gi + K) : 2 * K;
+    double s = 0.0;
+    for (int d = d0; d <= d1; ++d) s += band[(int64_t)d * ld + i] * xh[i + d];
+    y[i] = s;
+}
+
+hipError_t launch_band_matvec(int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
+                              const double *xh, double *y, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_matvec, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_global, row0, n, K, band,
+                       ld, xh, y);
+    return hipGetLastError();
+}
+
+// ---- spike tips by K pairs of sweeps (setup) -------------------------------------------------
+// C_p(a,b) = A[s+a, s-K+b]  -> band slot d = b - a        (a <= b)
+// B_p(a,b) = A[e-K+a, e+b]  -> band slot d = 2K + b - a   (b <= a)
+__device__ __forceinline__ bool has_top(const ChainDesc &cd, int64_t grow0) { return grow0 + cd.row0 > 0; }
+__device__ __forceinline__ bool has_bot(const ChainDesc &cd, int64_t grow0, int64_t n_global)
+{
+    return grow0 + cd.row0 + cd.nrows < n_global;
+}
+
+__global__ void k_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs)
+{
+    const int p = blockIdx.x;
+    const ChainDesc cd = chains[p];
+    for (int a = threadIdx.x; a < K; a += blockDim.x) {
+        if (which == 0) {
+            if (!has_top(cd, grow0)) continue;
+            const int64_t r = cd.row0 + a;
+            rhs[r] = (a <= col) ? band[(int64_t)(col - a) * ld + r] : 0.0;
+        } else {
+            if (!has_bot(cd, grow0, n_global)) continue;
+            const int64_t r = cd.row0 + cd.nrows - K + a;
+            rhs[r] = (col <= a) ? band[(int64_t)(2 * K + col - a) * ld + r] : 0.0;
+        }
+    }
+}
+
+hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tip_rhs, dim3(nchains), dim3(64), 0, st, band, ld, K, n_global, grow0, chains, nchains, which,
+                       col, rhs);
+    return hipGetLastError();
+}
+
+__global__ void k_tip_gather(const double *sol, int K, const ChainDesc *chains, int which, int col, double *out)
+{
+    const int p = blockIdx.x;
+    const ChainDesc cd = chains[p];
+    for (int a = threadIdx.x; a < K; a += blockDim.x) {
+        const int64_t r = (which == 0) ? cd.row0 + a : cd.row0 + cd.nrows - K + a;
+        out[((int64_t)p * K + a) * K + col] = sol[r];
+    }
+}
+
+hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, int nchains, int which, int col,
+                             double *out, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tip_gather, dim3(nchains), dim3(64), 0, st, sol, K, chains, which, col, out);
+    return hipGetLastError();
+}
+
+__global__ void k_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                                  const ChainDesc *chains, int which, double *out)
+{
+    const int p = blockIdx.x;
+    const ChainDesc cd = chains[p];
+    const bool on = which == 0 ? has_top(cd, grow0) : has_bot(cd, grow0, n_global);
+    for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
+        const int a = t % K, b = t / K;  // column-major: out[b*K + a]
+        double v = 0.0;
+        if (on) {
+            if (which == 0) { if (a <= b) v = band[(int64_t)(b - a) * ld + cd.row0 + a]; }
+            else { if (b <= a) v = band[(int64_t)(2 * K + b - a) * ld + cd.row0 + cd.nrows - K + a]; }
+        }
+        out[(int64_t)p * K * K + t] = v;
+    }
+}
+
+hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
+                                  const ChainDesc *chains, int nchains, int which, double *out, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_coupling_blocks, dim3(nchains), dim3(256), 0, st, band, ld, K, n_global, grow0, chains, which,
+                       out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// interface systems
+// ------------------------------------------------------------------------------------------
+// work: per interface K x 2K row-major [S | I] -> [I | S^{-1}] by Gauss-Jordan with partial pivoting
+__global__ __launch_bounds__(256) void k_iface_setup(int K, const double *Wall, const double *Vall, double *WTall,
+                                                     double *VTall, double *STall, double *workall, int *flag)
+{
+    extern __shared__ double sh[];
+    double *rowk = sh;           // 2K
+    double *colk = sh + 2 * K;   // K
+    __shared__ double rmax[256];
+    __shared__ int ridx[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int64_t kk = (int64_t)K * K;
+    const double *W = Wall + f * kk, *V = Vall + f * kk;
+    double *WT = WTall + f * kk, *VT = VTall + f * kk, *ST = STall + f * kk;
+    double *M = workall + f * 2 * kk;
+    const int K2 = 2 * K;
+    for (int t = tid; t < K * K; t += 256) {
+        const int a = t / K, b = t % K;
+        double s = (a == b) ? 1.0 : 0.0;
+        for (int c = 0; c < K; ++c) s -= W[a * K + c] * V[c * K + b];
+        M[a * K2 + b] = s;
+        M[a * K2 + K + b] = (a == b) ? 1.0 : 0.0;
+        WT[b * K + a] = W[t];
+        VT[b * K + a] = V[t];
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int k = 0; k < K; ++k) {
+        double best = -1.0;
+        int bi = k;
+        for (int r = k + tid; r < K; r += 256) {
+            const double v = fabs(M[r * K2 + k]);
+            if (v > best) { best = v; bi = r; }
+        }
+        rmax[tid] = best; ridx[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                if (rmax[tid + o] > rmax[tid] || (rmax[tid + o] == rmax[tid] && ridx[tid + o] < ridx[tid])) {
+                    rmax[tid] = rmax[tid + o]; ridx[tid] = ridx[tid + o];
+                }
+            }
+            __syncthreads();
+        }
+        const int pr = ridx[0];
+        const double pv = rmax[0];
+        if (!(pv > 0.0)) { bad = 1; break; }
+        // swap rows k and pr, scale pivot row
+        for (int cI = tid; cI < K2; cI += 256) {
+            const double a = M[pr * K2 + cI], b = M[k * K2 + cI];
+            if (pr != k) M[pr * K2 + cI] = b;
+            rowk[cI] = a;
+        }
+        __syncthreads();
+        const double inv = 1.0 / rowk[k];
+        for (int cI = tid; cI < K2; cI += 256) {
+            const double v = rowk[cI] * inv;
+            M[k * K2 + cI] = v;
+        }
+        for (int r = tid; r < K; r += 256) colk[r] = (r == k) ? 0.0 : M[r * K2 + k];
+        __syncthreads();
+        for (int cI = tid; cI < K2; cI += 256) rowk[cI] *= inv;
+        __syncthreads();
+        for (int t = tid; t < K * K2; t += 256) {
+            const int r = t / K2, cI = t % K2;
+            if (r != k) M[t] -= colk[r] * rowk[cI];
+        }
+        __syncthreads();
+    }
+    if (bad) { if (tid == 0) flag[f] = 1; return; }
+    for (int t = tid; t < K * K; t += 256) {
+        const int a = t / K, b = t % K;
+        ST[b * K + a] = M[a * K2 + K + b];
+    }
+}
+
+hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
+                              double *work, int *flag, hipStream_t st)
+{
+    if (nif <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_iface_setup, dim3(nif), dim3(256), (size_t)3 * K * sizeof(double), st, K, W, V, WT, VT, ST,
+                       work, flag);
+    return hipGetLastError();
+}
+
+// y[a] = sum_c MT[c*K + a] * x[c];  256 threads = nparts groups of KA lanes, partial sums via LDS
+__device__ __forceinline__ double iface_matvec(const double *MT, const double *xs, int K, int KA, int nparts, int a,
+                                               int part, double *redb)
+{
+    double acc = 0.0;
+    if (a < K && MT != nullptr)
+        for (int c = part; c < K; c += nparts) acc = fma(MT[(int64_t)c * K + a], xs[c], acc);
+    redb[threadIdx.x] = acc;
+    __syncthreads();
+    double s = 0.0;
+    for (int q = 0; q < nparts; ++q) s += redb[q * KA + a];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_iface_apply(int K, const IfaceDesc *ifs)
+{
+    extern __shared__ double sh[];
+    double *gb = sh, *gt = sh + K, *v1 = sh + 2 * K, *v2 = sh + 3 * K;
+    __shared__ double redb[256];
+    const IfaceDesc d = ifs[blockIdx.x];
+    const int tid = threadIdx.x;
+    int KA = 1;
+    while (KA < K) KA <<= 1;
+    const int nparts = 256 / KA;
+    const int a = tid % KA, part = tid / KA;
+    for (int t = tid; t < K; t += 256) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
+    __syncthreads();
+    // t = gt - W gb
+    double s = iface_matvec(d.WT, gb, K, KA, nparts, a, part, redb);
+    if (part == 0 && a < K) v1[a] = gt[a] - s;
+    __syncthreads();
+    // xt = S^{-1} t
+    s = iface_matvec(d.ST, v1, K, KA, nparts, a, part, redb);
+    if (part == 0 && a < K) v2[a] = s;  // v2 = xt
+    __syncthreads();
+    // xb = gb - V xt
+    s = iface_matvec(d.VT, v2, K, KA, nparts, a, part, redb);
+    if (part == 0 && a < K) v1[a] = gb[a] - s;  // v1 = xb
+    __syncthreads();
+    if (d.corr_top != nullptr) {
+        s = iface_matvec(d.CT, v1, K, KA, nparts, a, part, redb);
+        if (part == 0 && a < K) d.corr_top[a] = s;
+    }
+    if (d.corr_bot != nullptr) {
+        s = iface_matvec(d.BT, v2, K, KA, nparts, a, part, redb);
+        if (part == 0 && a < K) d.corr_bot[a] = s;
+    }
+}
+
+hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st)
+{
+    if (nif <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(256), (size_t)4 * K * sizeof(double), st, K, ifs);
+    return hipGetLastError();
+}
+
+}  // namespace spike

@@ -65,6 +65,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SpikeError("libspike_mi355.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
                          % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME).  A process must hold ONE HIP runtime, so when
+    # torch is installed it is imported first and this library then binds to the runtime torch loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.spike_create.argtypes = [C.POINTER(vp)]

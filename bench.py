@@ -31,7 +31,20 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 
 
 def alg_bytes(N, K, p, P):
-    return p * ((2 * K + 1) * N * 8 + 2 * N * 8) + max(P - 1, 0) * ((2 * K) ** 2 + 4 * K) * 8
+    red = max(P - 1, 0) * ((2 * K) ** 2 + 4 * K) * 8 if p == 2 else 0  # reduced-system term: coupled variant only
+    return p * ((2 * K + 1) * N * 8 + 2 * N * 8) + red
+
+
+def pmc_traffic(N, K, world):
+    """HBM bytes per pass (forward+backward k_sweep launch) from the committed rocprofv3 PMC passes
+    (profiles/pmc_current.json, produced by tools/parse_pmc.py with the gfx950 FETCH_SIZE x2 correction)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+        if d["N"] == N and d["K"] == K and world == 1:
+            return d["traffic_per_pass_bytes"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
@@ -194,7 +207,7 @@ def main():
             "ksp": ksp,
             "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(N, K, world),
                          "alg_bytes_per_pass": pass_bytes, "pass_ms": pass_ms},
         }
         if not args.no_cpu and world == 1:

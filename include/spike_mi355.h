@@ -90,6 +90,10 @@ int spike_set_stream(spike_handle h, void *hip_stream);
 int spike_comm_unique_id(char id[SPIKE_UNIQUE_ID_BYTES]); /* rank 0 creates, host code broadcasts */
 /* Joins nranks handles.  Must precede setup.  row0/n_global describe this rank's row block. */
 int spike_comm_init(spike_handle h, int nranks, int rank, const char id[SPIKE_UNIQUE_ID_BYTES]);
+/* Test transport: the nranks handles are driven by nranks host THREADS of one process that share one
+ * GPU (RCCL refuses two ranks on one device).  Same algorithm, buffers and call order as the RCCL
+ * transport; bytes move by hipMemcpy behind a host barrier.  `group` names the communicator.       */
+int spike_comm_init_local(spike_handle h, int nranks, int rank, int group);
 
 /* ---- setup ------------------------------------------------------------------------- */
 /* Factor the local rows [row0,row0+n_local) of an n_global system.  The local band holds the

@@ -26,7 +26,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/spike_mi355.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "spike_create", "spike_destroy", "spike_reset", "spike_last_error", "spike_set_option", "spike_set_stream",
-    "spike_comm_unique_id", "spike_comm_init", "spike_setup_band", "spike_setup_csr", "spike_apply", "spike_gmres",
+    "spike_comm_unique_id", "spike_comm_init", "spike_comm_init_local", "spike_setup_band", "spike_setup_csr", "spike_apply", "spike_gmres",
     "spike_band_matvec", "spike_gen_band", "spike_get_info", "spike_view", "spike_get_tips", "spike_last_sweep_ms",
 ]
 
@@ -82,6 +82,7 @@ def lib():
     L.spike_set_stream.argtypes = [vp, vp]
     L.spike_comm_unique_id.argtypes = [C.c_char_p]
     L.spike_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.spike_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.spike_setup_band.argtypes = [vp, i64, i64, i64, C.c_int, vp, i64, C.c_int]
     L.spike_setup_csr.argtypes = [vp, i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                   C.POINTER(C.c_double)]
@@ -170,6 +171,9 @@ class Spike:
 
     def comm_init(self, nranks, rank, uid):
         self._chk(self.L.spike_comm_init(self.h, nranks, rank, uid))
+
+    def comm_init_local(self, nranks, rank, group=0):
+        self._chk(self.L.spike_comm_init_local(self.h, nranks, rank, group))
 
     def setup_band(self, band, n_global=None, row0=0):
         nd, n = band.shape

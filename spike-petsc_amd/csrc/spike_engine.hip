@@ -15,6 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +57,30 @@ static bool rccl_load()
 }
 enum { NCCL_FLOAT64 = 8, NCCL_MAX = 2, NCCL_SUM = 0 };
 
+// ---- in-process loopback communicator (test transport) ----------------------------------------
+// Ranks are host threads of ONE process that share one GPU.  Same call sites, same buffers and the
+// same ordering as the RCCL transport; only the byte movement differs (hipMemcpy between the
+// ranks' device buffers behind a host barrier).  It exists so that the N>1 algorithm can be
+// verified on a one-GPU box (RCCL refuses two ranks on one device).
+struct LocalComm {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long gen = 0;
+    std::vector<const double *> send;
+    std::vector<double> host;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long g = gen;
+        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+static std::mutex g_local_mutex;
+static std::map<int, std::shared_ptr<LocalComm>> g_local;
+
 // ---- handle ---------------------------------------------------------------------------------------
 struct spike_handle_s {
     // options
@@ -66,6 +94,7 @@ struct spike_handle_s {
     // communicator
     int nranks = 1, rank = 0;
     ncclComm_t_ comm = nullptr;
+    std::shared_ptr<LocalComm> lcomm;  // loopback transport (tests)
     // problem
     bool ready = false;
     int64_t n_global = 0, row0 = 0, n = 0;
@@ -134,6 +163,57 @@ static hipError_t dalloc(T **p, size_t count)
     *p = nullptr;
     if (count == 0) count = 1;
     return hipMalloc((void **)p, count * sizeof(T));
+}
+
+// ---- collectives: RCCL, or the loopback transport -------------------------------------------------
+static int coll_allgather(spike_handle h, const double *send, double *recv, size_t count)
+{
+    if (h->nranks == 1) return SPIKE_OK;
+    if (h->lcomm) {
+        LocalComm &c = *h->lcomm;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        c.send[h->rank] = send;
+        c.barrier();
+        for (int r = 0; r < c.n; ++r)
+            HIPCHK(hipMemcpyAsync(recv + (size_t)r * count, c.send[r], sizeof(double) * count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        c.barrier();
+        return SPIKE_OK;
+    }
+    NCCLCHK(g_rccl.AllGather(send, recv, count, NCCL_FLOAT64, h->comm, h->stream));
+    return SPIKE_OK;
+}
+
+static int coll_allreduce(spike_handle h, double *buf, size_t count, int op)
+{
+    if (h->nranks == 1) return SPIKE_OK;
+    if (h->lcomm) {
+        LocalComm &c = *h->lcomm;
+        std::vector<double> mine(count);
+        HIPCHK(hipMemcpyAsync(mine.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        {
+            std::lock_guard<std::mutex> lk(c.m);
+            if (c.host.size() < (size_t)c.n * count) c.host.resize((size_t)c.n * count);
+        }
+        c.barrier();
+        for (size_t i = 0; i < count; ++i) c.host[(size_t)h->rank * count + i] = mine[i];
+        c.barrier();
+        for (size_t i = 0; i < count; ++i) {
+            double a = c.host[i];
+            for (int r = 1; r < c.n; ++r) {
+                const double v = c.host[(size_t)r * count + i];
+                a = (op == NCCL_MAX) ? (v > a ? v : a) : a + v;
+            }
+            mine[i] = a;
+        }
+        c.barrier();
+        HIPCHK(hipMemcpyAsync(buf, mine.data(), sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return SPIKE_OK;
+    }
+    NCCLCHK(g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT64, op, h->comm, h->stream));
+    return SPIKE_OK;
 }
 
 static void free_factors(spike_handle h)
@@ -225,6 +305,20 @@ extern "C" int spike_comm_init(spike_handle h, int nranks, int rank, const char 
     ncclUniqueId_ u;
     memcpy(u.internal, id, SPIKE_UNIQUE_ID_BYTES);
     NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    return SPIKE_OK;
+}
+
+extern "C" int spike_comm_init_local(spike_handle h, int nranks, int rank, int group)
+{
+    if (!h || nranks < 1 || rank < 0 || rank >= nranks) return SPIKE_ERR_ARG;
+    if (h->ready) return fail(h, SPIKE_ERR_STATE, "spike_comm_init_local must precede setup");
+    h->nranks = nranks;
+    h->rank = rank;
+    if (nranks == 1) return SPIKE_OK;
+    std::lock_guard<std::mutex> lk(g_local_mutex);
+    auto &c = g_local[group];
+    if (!c || c->n != nranks) { c = std::make_shared<LocalComm>(); c->n = nranks; c->send.assign(nranks, nullptr); }
+    h->lcomm = c;
     return SPIKE_OK;
 }
 
@@ -380,7 +474,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     double *dScal = nullptr;
     HIPCHK(dalloc(&dScal, 2));
     HIPCHK(launch_absmax_diag(h->dA, h->ldA, K, n, dScal, st));
-    if (h->nranks > 1) NCCLCHK(g_rccl.AllReduce(dScal, dScal, 1, NCCL_FLOAT64, NCCL_MAX, h->comm, st));
+    if ((rc = coll_allreduce(h, dScal, 1, NCCL_MAX))) return rc;
     double dmax = 0.0;
     HIPCHK(hipMemcpyAsync(&dmax, dScal, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -473,7 +567,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * (2 * kk > (size_t)2 * K ? 2 * kk : (size_t)2 * K)));
             HIPCHK(hipMemcpyAsync(h->dSend, h->dWt, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(h->dSend + kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
-            NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, 2 * kk, NCCL_FLOAT64, h->comm, st));
+            if ((rc = coll_allgather(h, h->dSend, h->dRecv, 2 * kk))) return rc;
             int idx = nif_local;
             if (h->rank > 0) {  // interface with the previous rank: V = prev rank's V_last, W = my W_first
                 ib_prev = idx++;
@@ -551,7 +645,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
         const bool multi = h->nranks > 1;
         hipLaunchKernelGGL(k_gather_tips, dim3(h->P), dim3(64), 0, st, y, h->K, h->dChains, h->P, h->dTips, multi ? h->dSend : nullptr);
         HIPCHK(hipGetLastError());
-        if (multi) NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, (size_t)2 * h->K, NCCL_FLOAT64, h->comm, st));
+        if (multi && (rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K))) return rc;
         HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfs, st));
         rc = run_pass(h, x, y, true);
         if (rc) return rc;
@@ -602,7 +696,7 @@ static int matvec_dev(spike_handle h, const double *x, double *y)
     const bool multi = h->nranks > 1;
     if (multi && K > 0) {
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, x, h->n, K, h->dSend);
-        NCCLCHK(g_rccl.AllGather(h->dSend, h->dRecv, (size_t)2 * K, NCCL_FLOAT64, h->comm, st));
+        { int rc2 = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K); if (rc2) return rc2; }
     }
     hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh);
     HIPCHK(hipGetLastError());
@@ -628,8 +722,7 @@ extern "C" int spike_gen_band(void *stream, int64_t n_global, int K, uint64_t se
 // ---- GMRES -----------------------------------------------------------------------------------------------------
 static int dist_sum(spike_handle h, double *dvals, int count)
 {
-    if (h->nranks > 1) NCCLCHK(g_rccl.AllReduce(dvals, dvals, (size_t)count, NCCL_FLOAT64, NCCL_SUM, h->comm, h->stream));
-    return SPIKE_OK;
+    return coll_allreduce(h, dvals, (size_t)count, NCCL_SUM);
 }
 
 extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int restart, double rtol, int maxit, int use_pc,

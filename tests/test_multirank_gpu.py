@@ -1,0 +1,94 @@
+"""N>1 algorithm on ONE GPU: ranks are host threads joined by the library's loopback transport
+(spike_comm_init_local) -- same buffers, same call order, same interface/halo logic as the RCCL path.
+The sharded result must equal the single-handle result (and the oracle) for the same global partitioning."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_group = [100]
+
+
+def _run_ranks(spike, G, fn):
+    """fn(rank, sp) in G threads; returns list of results; re-raises the first exception."""
+    _group[0] += 1
+    grp = _group[0]
+    out, err = [None] * G, [None] * G
+
+    def work(r):
+        try:
+            sp = spike.Spike(partitions=0)
+            sp.comm_init_local(G, r, grp)
+            out[r] = fn(r, sp)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(not t.is_alive() for t in th), "a rank hung"
+    return out
+
+
+def _split(N, G):
+    nblk = (N + 63) // 64
+    return [(nblk * r // G) * 64 for r in range(G)] + [N]
+
+
+@pytest.mark.parametrize("G,N,K,Pl", [(2, 16384, 16, 4), (2, 32768, 128, 2), (4, 32768, 40, 2), (3, 24576, 8, 4), (2, 8192, 1, 2)])
+@pytest.mark.parametrize("variant", ["coupled", "decoupled"])
+def test_sharded_apply_equals_single_and_oracle(spike, oracle, G, N, K, Pl, variant):
+    import torch
+    band = oracle.gen_band(N, K, delta=0.8)
+    f = oracle.gen_vec(N)
+    cuts = _split(N, G)
+
+    def fn(r, sp):
+        sp.set_option("partitions", Pl)
+        sp.set_option("variant", variant)
+        r0, r1 = cuts[r], cuts[r + 1]
+        sp.setup_band(np.ascontiguousarray(band[:, r0:r1]), n_global=N, row0=r0)
+        x = sp.apply(torch.from_numpy(f[r0:r1].copy()).cuda())
+        torch.cuda.synchronize()
+        i = sp.info()
+        assert i.nranks == G and i.rank == r and i.n_global == N and i.row0 == r0
+        return x.cpu().numpy()
+
+    x = np.concatenate(_run_ranks(spike, G, fn))
+    ref = oracle.Spike(band, G * Pl).apply(f, 1 if variant == "coupled" else 0)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    single = spike.Spike(partitions=G * Pl, variant=variant).setup_band(band).apply(f)
+    assert np.linalg.norm(x - single) <= 1e-12 * np.linalg.norm(single)
+
+
+def test_sharded_gmres_and_matvec(spike, oracle):
+    import torch
+    G, N, K, Pl = 2, 32768, 32, 8
+    band = oracle.gen_band(N, K, delta=0.8)
+    u = oracle.gen_vec(N, seed=9)
+    b = oracle.band_matvec(band, u)
+    cuts = _split(N, G)
+
+    def fn(r, sp):
+        sp.set_option("partitions", Pl)
+        sp.set_option("variant", "decoupled")
+        r0, r1 = cuts[r], cuts[r + 1]
+        sp.setup_band(np.ascontiguousarray(band[:, r0:r1]), n_global=N, row0=r0)
+        y = sp.matvec(torch.from_numpy(u[r0:r1].copy()).cuda())
+        x = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
+        it, rn, ms, ok = sp.gmres(torch.from_numpy(b[r0:r1].copy()).cuda(), x, restart=30, rtol=1e-8, maxit=200)
+        return y.cpu().numpy(), x.cpu().numpy(), it, ok
+
+    res = _run_ranks(spike, G, fn)
+    y = np.concatenate([r[0] for r in res])
+    x = np.concatenate([r[1] for r in res])
+    assert np.linalg.norm(y - b) <= 1e-14 * np.linalg.norm(b)          # halo exchange of the mat-vec
+    assert res[0][2] == res[1][2] and res[0][3] and res[1][3]          # both ranks agree on the iteration count
+    xo, ito, rno, hist, oko = oracle.gmres(band, b, oracle.Spike(band, G * Pl), variant=0, rtol=1e-8, maxit=200)
+    assert abs(res[0][2] - ito) <= 1
+    assert np.linalg.norm(x - u) <= 1e-6 * np.linalg.norm(u)

@@ -122,6 +122,26 @@ int spike_apply(spike_handle h, const double *x, double *y, int on_device);
 int spike_gmres(spike_handle h, const double *b, double *x, int restart, double rtol, int maxit, int use_pc,
                 int *iters, double *rnorm, double *solve_ms);
 
+/* Optional CSR operator for spike_gmres: the reference preconditions the FULL matrix A with its band
+ * (KSPSetOperators(ksp,A,B), src/testbed2.c:126).  Host 0-based int64 CSR, copied to the device; replaces the
+ * kept band as the operator until spike_clear_operator.  May be set on a handle without factors
+ * (then spike_gmres needs use_pc = 0).  Single rank.                                              */
+int spike_set_operator_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a);
+int spike_clear_operator(spike_handle h);
+
+/* raw device memory for C hosts that have no HIP headers (the host mirror uses these) */
+int spike_dev_malloc(void **p, size_t bytes);
+int spike_dev_free(void *p);
+int spike_dev_upload(void *dev_dst, const void *host_src, size_t bytes);
+int spike_dev_download(void *host_dst, const void *dev_src, size_t bytes);
+
+/* host steps of spike_setup_csr, usable on their own: the reference's half-bandwidth rule
+ * (src/matbanded.c:38-56,104-105) and the CSR -> diagonal-major band conversion                     */
+int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int kmax, double frac,
+                     int *k_out, double *frac_out);
+int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int K, double *band,
+                      int64_t ld);
+
 /* ---- helpers (device) ----------------------------------------------------------------------- */
 /* y = A x with the band kept at setup (device pointers, local rows; halo via RCCL when nranks>1) */
 int spike_band_matvec(spike_handle h, const double *x, double *y);

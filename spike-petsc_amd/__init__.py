@@ -28,6 +28,8 @@ ABI_SYMBOLS = [
     "spike_create", "spike_destroy", "spike_reset", "spike_last_error", "spike_set_option", "spike_set_stream",
     "spike_comm_unique_id", "spike_comm_init", "spike_comm_init_local", "spike_setup_band", "spike_setup_csr", "spike_apply", "spike_gmres",
     "spike_band_matvec", "spike_gen_band", "spike_get_info", "spike_view", "spike_get_tips", "spike_last_sweep_ms",
+    "spike_set_operator_csr", "spike_clear_operator", "spike_dev_malloc", "spike_dev_free", "spike_dev_upload",
+    "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band",
 ]
 
 

@@ -120,6 +120,12 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dHalo = nullptr;                              // matvec halo: [K left | K right]
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
+    // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
+    int64_t op_n = 0, op_nnz = 0;
+    int64_t *op_ia = nullptr;
+    int32_t *op_ja = nullptr;
+    double *op_a = nullptr;
+    int op_tpr = 1;
     // gmres workspace
     double *dV = nullptr, *dW = nullptr, *dZ = nullptr, *dDots = nullptr, *dCoef = nullptr;
     int gm_restart = 0;
@@ -247,10 +253,12 @@ extern "C" int spike_reset(spike_handle h)
     return SPIKE_OK;
 }
 
+extern "C" int spike_clear_operator(spike_handle h);
 extern "C" int spike_destroy(spike_handle h)
 {
     if (!h) return SPIKE_ERR_ARG;
     spike_reset(h);
+    spike_clear_operator(h);
     if (h->comm && g_rccl.ok()) g_rccl.CommDestroy(h->comm);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -691,6 +699,10 @@ extern "C" int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunc
 static int matvec_dev(spike_handle h, const double *x, double *y)
 {
     hipStream_t st = h->stream;
+    if (h->op_n > 0) {
+        HIPCHK(launch_csr_matvec(h->op_n, h->op_ia, h->op_ja, h->op_a, h->op_tpr, x, y, st));
+        return SPIKE_OK;
+    }
     const int K = h->K;
     if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
     const bool multi = h->nranks > 1;
@@ -708,7 +720,11 @@ extern "C" int spike_band_matvec(spike_handle h, const double *x, double *y)
 {
     if (!h || !x || !y) return SPIKE_ERR_ARG;
     if (!h->ready || !h->dA) return fail(h, SPIKE_ERR_STATE, "spike_band_matvec needs a setup with the band kept");
-    return matvec_dev(h, x, y);
+    const int64_t keep = h->op_n;
+    h->op_n = 0;  // the band, not the optional CSR operator
+    const int rc = matvec_dev(h, x, y);
+    h->op_n = keep;
+    return rc;
 }
 
 extern "C" int spike_gen_band(void *stream, int64_t n_global, int K, uint64_t seed, double delta, int64_t row0,
@@ -729,9 +745,11 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
                            int *iters, double *rnorm, double *solve_ms)
 {
     if (!h || !b || !x || restart < 1 || maxit < 0) return SPIKE_ERR_ARG;
-    if (!h->ready || !h->dA) return fail(h, SPIKE_ERR_STATE, "spike_gmres needs a setup with the band kept");
+    if (use_pc && !h->ready) return fail(h, SPIKE_ERR_STATE, "spike_gmres with use_pc needs a setup");
+    if (h->op_n == 0 && (!h->ready || !h->dA)) return fail(h, SPIKE_ERR_STATE, "spike_gmres needs an operator: the band kept at setup or spike_set_operator_csr");
+    if (h->op_n > 0 && h->ready && h->op_n != h->n) return fail(h, SPIKE_ERR_ARG, "operator has %lld rows, preconditioner %lld", (long long)h->op_n, (long long)h->n);
     hipStream_t st = h->stream;
-    const int64_t n = h->n;
+    const int64_t n = h->op_n > 0 ? h->op_n : h->n;
     const int m = restart;
     if (h->gm_restart != m) {
         auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
@@ -827,6 +845,48 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
     if (rnorm) *rnorm = rn;
     return conv ? 0 : 1;
 }
+
+// ---- CSR operator + raw device memory helpers for C hosts without HIP headers --------------------------
+extern "C" int spike_clear_operator(spike_handle h)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    (void)hipStreamSynchronize(h->stream);
+    if (h->op_ia) (void)hipFree(h->op_ia);
+    if (h->op_ja) (void)hipFree(h->op_ja);
+    if (h->op_a) (void)hipFree(h->op_a);
+    h->op_ia = nullptr; h->op_ja = nullptr; h->op_a = nullptr; h->op_n = h->op_nnz = 0;
+    return SPIKE_OK;
+}
+
+extern "C" int spike_set_operator_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a)
+{
+    if (!h || n <= 0 || !ia || !ja || !a) return SPIKE_ERR_ARG;
+    if (h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "CSR operator is single-rank");
+    if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "operator too large");
+    spike_clear_operator(h);
+    const int64_t nnz = ia[n];
+    std::vector<int32_t> j32((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (ja[k] < 0 || ja[k] >= n) return fail(h, SPIKE_ERR_ARG, "column index out of range at %lld", (long long)k);
+        j32[(size_t)k] = (int32_t)ja[k];
+    }
+    HIPCHK(dalloc(&h->op_ia, (size_t)n + 1));
+    HIPCHK(dalloc(&h->op_ja, (size_t)nnz));
+    HIPCHK(dalloc(&h->op_a, (size_t)nnz));
+    HIPCHK(hipMemcpyAsync(h->op_ia, ia, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->op_ja, j32.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->op_a, a, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->op_n = n; h->op_nnz = nnz;
+    const double avg = (double)nnz / (double)n;
+    h->op_tpr = avg > 48 ? 64 : avg > 12 ? 16 : avg > 3 ? 4 : 1;
+    return SPIKE_OK;
+}
+
+extern "C" int spike_dev_malloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 8) == hipSuccess ? SPIKE_OK : SPIKE_ERR_NOMEM; }
+extern "C" int spike_dev_free(void *p) { return hipFree(p) == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP; }
+extern "C" int spike_dev_upload(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP; }
+extern "C" int spike_dev_download(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP; }
 
 // ---- CSR entry: band extraction (reference src/matbanded.c:22-107) then setup ----------------------------
 extern "C" int spike_csr_extract_setup(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja,

@@ -114,4 +114,36 @@ hipError_t launch_residual(const double *b, const double *ax, double *r, int64_t
     return hipGetLastError();
 }
 
+// y = A x for a CSR operator (the un-banded A of /root/reference/src/testbed2.c:125-128).  TPR lanes share a row
+// (TPR = 1, 4, 16, 64 picked from the mean row length) so that short circuit-matrix rows do not idle a wave.
+template <int TPR>
+__global__ __launch_bounds__(256) void k_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a,
+                                                    const double *x, double *y)
+{
+    const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / TPR;
+    const int sub = threadIdx.x % TPR;
+    double s = 0.0;
+    if (row < n) {
+        const int64_t e = ia[row + 1];
+        for (int64_t k = ia[row] + sub; k < e; k += TPR) s = fma(a[k], x[ja[k]], s);
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_down(s, o, TPR);
+    if (row < n && sub == 0) y[row] = s;
+}
+
+hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int tpr, const double *x,
+                             double *y, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n * tpr + 255) / 256);
+    switch (tpr) {
+    case 1: hipLaunchKernelGGL((k_csr_matvec<1>), dim3(grid), dim3(256), 0, st, n, ia, ja, a, x, y); break;
+    case 4: hipLaunchKernelGGL((k_csr_matvec<4>), dim3(grid), dim3(256), 0, st, n, ia, ja, a, x, y); break;
+    case 16: hipLaunchKernelGGL((k_csr_matvec<16>), dim3(grid), dim3(256), 0, st, n, ia, ja, a, x, y); break;
+    default: hipLaunchKernelGGL((k_csr_matvec<64>), dim3(grid), dim3(256), 0, st, n, ia, ja, a, x, y); break;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace spike

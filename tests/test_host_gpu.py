@@ -1,0 +1,121 @@
+"""GPU tests of the host mirror: they read like /root/reference/src/testbed2.c -- register the plugins (:61-73),
+load/construct A, u = 1, b = A u (:110-122), KSPSetOperators(A,A), KSPSetFromOptions, KSPSolve (:125-128), report
+||x - u|| (:130-132) -- with everything selected through the options database, prefixes as the reference builds them
+(kspreorder.c:219-221 "reorder_", matbanded.c:279-281 "banded_")."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from matrices import circuit_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import torch
+    assert torch.cuda.is_available()
+    import spike_petsc_amd.host as H
+    H.chk(H.lib().SpikePetscRegisterAll())
+    return H
+
+
+def _testbed2(H, A, **opts):
+    """the body of testbed2.c main(): returns (error norm, iterations, reason, ksp handle kept alive for queries)"""
+    L = H.lib()
+    H.options(**opts)
+    n = A.shape[0]
+    M = H.Mat.from_scipy(A)
+    u, b, x = H.Vec(n), H.Vec(n), H.Vec(n)
+    H.chk(L.VecSet(u.h, 1.0))
+    H.chk(L.MatMult(M.h, u.h, b.h))
+    ksp = C.c_void_p()
+    H.chk(L.KSPCreate(C.byref(ksp)))
+    H.chk(L.KSPSetOperators(ksp, M.h, M.h))
+    H.chk(L.KSPSetFromOptions(ksp))
+    b0 = b.array.copy()
+    H.chk(L.KSPSolve(ksp, b.h, x.h))
+    assert np.array_equal(b.array, b0)          # KSPSolve_Reorder restores the caller's rhs (kspreorder.c:127)
+    H.chk(L.VecAXPY(x.h, -1.0, u.h))
+    err = C.c_double(0)
+    H.chk(L.VecNorm2(x.h, C.byref(err)))
+    its, reason = C.c_int64(0), C.c_int(0)
+    H.chk(L.KSPGetIterationNumber(ksp, C.byref(its)))
+    H.chk(L.KSPGetConvergedReason(ksp, C.byref(reason)))
+    return err.value, its.value, reason.value, ksp, M
+
+
+def test_banded_pc_on_banded_matrix(H, oracle):
+    # src/makefile:18: -ksp_type gmres -ksp_rtol 1.0e-5 -ksp_max_it 500 with -pc_type banded
+    N, K = 20000, 20
+    band = oracle.gen_band(N, K, delta=0.8)
+    A = sp.diags([band[d, max(0, K - d):N - max(0, d - K)] for d in range(2 * K + 1)], [d - K for d in range(2 * K + 1)]).tocsr()
+    err, its, reason, ksp, M = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=500, pc_type="banded",
+                                         banded_pc_spike_partitions=8)
+    assert reason == 2 and its <= 12 and err <= 1e-4 * np.sqrt(N)
+    L = H.lib()
+    pc = C.c_void_p()
+    H.chk(L.KSPGetPC(ksp, C.byref(pc)))
+    k, f, kmax, frac = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
+    H.chk(L.PCBandedGetInfo(pc, C.byref(k), C.byref(f), C.byref(kmax), C.byref(frac)))
+    ko, fo, *_ = oracle.band_extract(N, A.indptr, A.indices, A.data, 50, 0.95)
+    assert (k.value, f.value, kmax.value, frac.value) == (ko, fo, 50, 0.95)     # defaults of matbanded.c:261-262
+    # unpreconditioned GMRES needs many more iterations on the same system
+    err0, its0, reason0, *_ = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=500, pc_type="none")
+    assert its0 > its
+    H.chk(L.KSPDestroy(C.byref(ksp)))
+
+
+def test_pcapply_banded_host_vectors_match_oracle(H, oracle):
+    L = H.lib()
+    N, K, P = 12000, 12, 6
+    band = oracle.gen_band(N, K, delta=0.9)
+    A = sp.diags([band[d, max(0, K - d):N - max(0, d - K)] for d in range(2 * K + 1)], [d - K for d in range(2 * K + 1)]).tocsr()
+    H.options(pc_banded_kmax=50, pc_banded_frac=1.0, banded_pc_spike_partitions=P)
+    M = H.Mat.from_scipy(A)
+    pc = C.c_void_p()
+    H.chk(L.PCCreate(C.byref(pc)))
+    H.chk(L.PCSetType(pc, b"banded"))
+    H.chk(L.PCSetOperators(pc, M.h, M.h))
+    H.chk(L.PCSetFromOptions(pc))
+    H.chk(L.PCSetUp(pc))
+    f = oracle.gen_vec(N)
+    x, y = H.Vec(values=f), H.Vec(N)
+    H.chk(L.PCApply(pc, x.h, y.h))
+    ref = oracle.Spike(band, P).apply(f, 1)
+    assert np.linalg.norm(y.array - ref) <= 1e-10 * np.linalg.norm(ref)
+    assert L.PCApply(pc, x.h, x.h) != 0                                   # x == y is an error, as in PETSc
+    H.chk(L.PCBandedSetMaxHalfBandwidth(pc, 3))                           # the working setter (matbanded.c:215-223)
+    kmax = C.c_int64()
+    H.chk(L.PCBandedGetInfo(pc, None, None, C.byref(kmax), None))
+    assert kmax.value == 3
+    H.chk(L.PCDestroy(C.byref(pc)))
+
+
+def test_config4_pipeline_mc64_fiedler_band_gmres(H, oracle):
+    """BASELINE config 4 on the circuit-like stand-in (ASIC_320k is not available offline): MC64 (as a row
+    permutation: the matrix is unsymmetric) -> Fiedler -> band extraction (kmax 50) -> PCSPIKE inside GMRES,
+    selected purely through nested KSPREORDER options."""
+    L = H.lib()
+    n = 30000
+    A = circuit_like(n, seed=11)
+    assert (np.abs(A.diagonal()) == 0).sum() > n // 2          # the diagonal really is destroyed
+    opts = dict(ksp_type="reorder", mat_ordering_type="wbm", mat_wbm_rows=1,
+                reorder_ksp_type="reorder", reorder_mat_ordering_type="fiedler",
+                reorder_reorder_ksp_type="gmres", reorder_reorder_ksp_rtol=1e-5, reorder_reorder_ksp_max_it=500,
+                reorder_reorder_pc_type="banded", reorder_reorder_pc_banded_kmax=50,
+                reorder_reorder_banded_pc_spike_partitions=16)
+    err, its, reason, ksp, M = _testbed2(H, A, **opts)
+    assert reason == 2 and its <= 60 and err <= 1e-3 * np.sqrt(n), (err, its, reason)
+    # the orderings are the ones the stand-alone kernels give
+    r, c = C.c_void_p(), C.c_void_p()
+    H.chk(L.KSPReorderGetOrdering(ksp, C.byref(r), C.byref(c)))
+    perm, *_ = H.mc64_job5(n, A.indptr, A.indices, A.data)
+    assert np.array_equal(H.is_indices(r), perm) and np.array_equal(H.is_indices(c), np.arange(n))
+    H.chk(L.KSPDestroy(C.byref(ksp)))
+    # without the reorderings the same banded PC is useless (band holds almost nothing of A)
+    err2, its2, reason2, ksp2, _ = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=60, pc_type="none")
+    assert reason2 != 2 or its2 > its
+    H.chk(L.KSPDestroy(C.byref(ksp2)))

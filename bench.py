@@ -15,8 +15,9 @@ allgather inside the library (spike_comm_init).
 
 Algorithmic bytes per PCApply (SURVEY.md 8d / BASELINE.md 3):
     BYTES(N,K,p) = p*[(2K+1)*N*8 + 2*N*8] + (P-1)*[(2K)^2 + 4K]*8      p = 1 decoupled, p = 2 coupled
-`value` = BYTES(N,K,p of the benchmarked variant) / time.  The JSON also carries the strict one-pass
-figure (BYTES(N,K,1)/time) and the other variant.
+`value` = BYTES(N,K,p the run really makes) / time: the coupled variant makes ONE pass when the library could keep the
+decayed part of the spikes (spike_info.passes == 1; the extra spike/interface bytes it reads are NOT counted),
+two passes when it has to re-solve.  The JSON also carries the strict one-pass figure (BYTES(N,K,1)/time).
 """
 import argparse
 import json
@@ -30,8 +31,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def alg_bytes(N, K, p, P):
-    red = max(P - 1, 0) * ((2 * K) ** 2 + 4 * K) * 8 if p == 2 else 0  # reduced-system term: coupled variant only
+def alg_bytes(N, K, p, P, coupled=True):
+    red = max(P - 1, 0) * ((2 * K) ** 2 + 4 * K) * 8 if coupled else 0  # reduced-system term: coupled variant only
     return p * ((2 * K + 1) * N * 8 + 2 * N * 8) + red
 
 
@@ -72,7 +73,7 @@ def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
     per = t / reps
     p = 2 if variant == 1 else 1
     return {
-        "value": alg_bytes(N, K, p, P) / per / 1e9, "unit": "GB/s", "cores": int(L.orc_num_threads()), "kind": "port",
+        "value": alg_bytes(N, K, p, P, variant == 1) / per / 1e9, "unit": "GB/s", "cores": int(L.orc_num_threads()), "kind": "port",
         "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition as on the GPU), "
                   "%s variant, %d applies, setup %.1f s not timed" % (N, K, P, rows_per_part,
                                                                      "coupled" if variant else "decoupled", reps, t_setup),
@@ -163,9 +164,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    p = 2 if args.variant == "coupled" else 1
-    gbps = alg_bytes(N, K, p, P_total) / (dt / args.steps) / 1e9
-    gbps_1 = alg_bytes(N, K, 1, P_total) / (dt / args.steps) / 1e9
+    p = int(info.passes)          # 1: decoupled, or coupled with stored spikes; 2: coupled re-solving
+    coupled = args.variant == "coupled"
+    gbps = alg_bytes(N, K, p, P_total, coupled) / (dt / args.steps) / 1e9
+    gbps_1 = alg_bytes(N, K, 1, P_total, coupled) / (dt / args.steps) / 1e9
 
     # dominant kernel: k_sweep (forward + backward launch = one pass over the factors of the local rows)
     n_pass = max(sweep_launches // 2, 1)
@@ -200,7 +202,8 @@ def main():
             "config": {"workload": "banded N=%d half-bw=%d fp64, SPIKE %s, %d partitions (%d/GPU), delta=%.2f, seed 12345"
                                    % (N, K, args.variant, P_total, info.P_local, args.delta),
                        "N": N, "K": K, "partitions": P_total, "variant": args.variant,
-                       "passes_over_factors": p, "rows_per_partition": n_local // info.P_local},
+                       "passes_over_factors": p, "rows_per_partition": n_local // info.P_local,
+                       "stored_spike_rows": int(info.spike_rows)},
             "GBps_single_pass_bytes": gbps_1,
             "max_abs_error_vs_exact_solution": err,
             "setup_s": setup_s,

@@ -72,6 +72,9 @@ typedef struct {
     double setup_ms;         /* wall time of the last setup (device work, synchronised) */
     int32_t k_extracted;     /* spike_setup_csr: chosen half-bandwidth (matbanded.c:104) */
     double frac_extracted;   /* spike_setup_csr: achieved norm fraction (matbanded.c:105) */
+    int32_t passes;          /* passes over the packed factors per apply: 1, or 2 (coupled variant re-solving) */
+    int32_t spike_rows;      /* rows kept of every spike (0: none, the coupled variant re-solves) */
+    int64_t spike_bytes;     /* bytes of stored spikes read per coupled apply */
 } spike_info;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -81,7 +84,10 @@ int spike_reset(spike_handle h); /* drop the factors, keep options and communica
 const char *spike_last_error(spike_handle h);
 
 /* keys: "partitions" (int >=1, or 0 = auto), "variant" ("decoupled"|"coupled"|0|1),
- *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1)    */
+ *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1),
+ *       "spike_storage" ("auto"|"off": keep the spikes' decayed part and apply the coupled variant in ONE pass
+ *        when they are short, else/off: second pass over the factors), "spike_tol" (relative drop level, 1e-17),
+ *       "profile" (0|1: record HIP events around the sweep launches)                                  */
 int spike_set_option(spike_handle h, const char *key, const char *value);
 /* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */
 int spike_set_stream(spike_handle h, void *hip_stream);

@@ -39,7 +39,7 @@ class SpikeInfo(C.Structure):
         ("P_local", C.c_int32), ("P_global", C.c_int32), ("variant", C.c_int32), ("rows_per_block", C.c_int32),
         ("waves_per_chain", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("nboost", i64),
         ("factor_bytes", i64), ("iface_bytes", i64), ("setup_ms", C.c_double), ("k_extracted", C.c_int32),
-        ("frac_extracted", C.c_double),
+        ("frac_extracted", C.c_double), ("passes", C.c_int32), ("spike_rows", C.c_int32), ("spike_bytes", i64),
     ]
 
 

@@ -89,6 +89,8 @@ struct spike_handle_s {
     double boost_rel = 1e-10;
     int keep_band = 1;
     int profile = 0;
+    int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
+    double spike_tol = 1e-17;   // relative magnitude below which spike rows are dropped
     hipStream_t stream = nullptr;
     std::string err;
     // communicator
@@ -117,6 +119,10 @@ struct spike_handle_s {
     double *dBT = nullptr, *dCT = nullptr;                // per chain, column-major
     double *dCorrTop = nullptr, *dCorrBot = nullptr;      // per chain, K
     double *dTips = nullptr;                              // per chain [gt(K) | gb(K)]
+    double *dWf = nullptr, *dVf = nullptr;                // stored spikes, per chain column-major K x m
+    double *dXb = nullptr, *dXt = nullptr;                // tip solutions, (P+2) x K (slot p+1 = chain p)
+    IfaceDesc *dIfsFast = nullptr;
+    int spike_m = 0;                                      // rows kept per spike (0 = re-solve variant)
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dHalo = nullptr;                              // matvec halo: [K left | K right]
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
@@ -229,6 +235,7 @@ static void free_factors(spike_handle h)
     h->ownA = false;
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
+    F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); h->spike_m = 0;
     F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dHalo); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
@@ -280,6 +287,8 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "boost") h->boost_rel = atof(val);
     else if (k == "keep_band") h->keep_band = atoi(val);
     else if (k == "profile") h->profile = atoi(val);
+    else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "spike_tol") h->spike_tol = atof(val);
     else return fail(h, SPIKE_ERR_ARG, "unknown option '%s'", key);
     return SPIKE_OK;
 }
@@ -334,8 +343,8 @@ extern "C" int spike_comm_init_local(spike_handle h, int nranks, int rank, int g
 static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
 {
     const int64_t nblk = (n + BLK - 1) / BLK;
-    int64_t minrows = (int64_t)8 * K;
-    if (minrows < 256) minrows = 256;
+    int64_t minrows = (int64_t)16 * K;  // spikes of the synthetic dominant systems die out over ~10 K rows
+    if (minrows < 512) minrows = 512;
     int64_t target = (int64_t)(2048 / cfg.NW) * cfg.CPW();  // ~8 waves on each of 256 CUs
     int64_t byrows = n / minrows;
     int64_t P = target < byrows ? target : byrows;
@@ -536,6 +545,42 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(dalloc(&sol, (size_t)n));
         const bool keep_prof = h->profile;
         h->profile = 0;
+        // ---- how far do the spikes reach?  probe the first and last column of W and of V
+        int m = 0;
+        double *dStat = nullptr;  // [absmax_in, absmax_out, probe absmax, extent(int)]
+        HIPCHK(dalloc(&dStat, 4));
+        HIPCHK(hipMemsetAsync(dStat, 0, 4 * sizeof(double), st));
+        int nmin = h->chains[0].nrows;
+        for (int p = 1; p < P; ++p) nmin = std::min<int>(nmin, h->chains[p].nrows);
+        if (h->spike_storage) {
+            for (int which = 0; which < 2; ++which) {
+                HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
+                for (int t = 0; t < 2; ++t) {
+                    const int col = t == 0 ? 0 : K - 1;
+                    if (t == 1 && K == 1) break;
+                    HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
+                    if ((rc = run_pass(h, rhs, sol, false))) return rc;
+                    HIPCHK(launch_absmax_diag(sol, n, 0, n, dStat + 2, st));
+                    double amax = 0.0;
+                    HIPCHK(hipMemcpyAsync(&amax, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    HIPCHK(launch_spike_extent(sol, h->dChains, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
+                }
+            }
+            int extent = 0;
+            HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            m = (int)(((int64_t)(extent * 1.06) + 64 + 63) / 64 * 64);  // 2 probed columns -> small margin; verified below
+            if (m > nmin) m = nmin;
+            // worth it only while the correction stays well below a pass over the factors
+            const double corr_bytes = 2.0 * m * (double)K * 8.0 * P;
+            const double pass_bytes = 2.0 * (double)h->ntiles * (double)cfg.tile_doubles() * 8.0;
+            if (corr_bytes > 0.6 * pass_bytes) m = 0;
+        }
+        if (m > 0) {
+            HIPCHK(dalloc(&h->dWf, (size_t)P * K * m));
+            HIPCHK(dalloc(&h->dVf, (size_t)P * K * m));
+        }
         for (int which = 0; which < 2; ++which) {
             HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
             for (int col = 0; col < K; ++col) {
@@ -543,11 +588,25 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 rc = run_pass(h, rhs, sol, false);
                 if (rc) return rc;
                 HIPCHK(launch_tip_gather(sol, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st));
+                if (m > 0) HIPCHK(launch_spike_gather(sol, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st));
             }
         }
         h->profile = keep_prof;
+        if (m > 0) {
+            double stat[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(stat, dStat, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            // anything of weight left outside the window?  then the spikes do not decay: keep the re-solve variant
+            if (m < nmin && stat[1] > 1e3 * h->spike_tol * stat[0]) {
+                (void)hipFree(h->dWf); (void)hipFree(h->dVf);
+                h->dWf = h->dVf = nullptr;
+                m = 0;
+            }
+        }
+        h->spike_m = m;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipFree(sol));
+        HIPCHK(hipFree(dStat));
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 0, h->dCT, st));
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 1, h->dBT, st));
 
@@ -622,8 +681,26 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             d.BT = h->dBT + (size_t)(P - 1) * kk; d.CT = nullptr;
             d.corr_bot = h->dCorrBot + (size_t)(P - 1) * K; d.corr_top = nullptr;
         }
+        for (auto &d : ifs) { d.xb_out = nullptr; d.xt_out = nullptr; }
         HIPCHK(dalloc(&h->dIfs, (size_t)nif));
         HIPCHK(hipMemcpyAsync(h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+        if (h->spike_m > 0) {
+            // one-pass variant: the interface kernel only has to deliver the tip solutions
+            HIPCHK(dalloc(&h->dXb, (size_t)(P + 2) * K));
+            HIPCHK(dalloc(&h->dXt, (size_t)(P + 2) * K));
+            HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
+            HIPCHK(hipMemsetAsync(h->dXt, 0, sizeof(double) * (P + 2) * K, st));
+            std::vector<IfaceDesc> ff(ifs);
+            for (auto &d : ff) { d.BT = d.CT = nullptr; d.corr_bot = d.corr_top = nullptr; }
+            for (int i = 0; i < nif_local; ++i) {
+                ff[i].xb_out = h->dXb + (size_t)(i + 1) * K;  // bottom tip of chain i
+                ff[i].xt_out = h->dXt + (size_t)(i + 2) * K;  // top tip of chain i+1
+            }
+            if (ib_prev >= 0) { ff[ib_prev].xb_out = h->dXb; ff[ib_prev].xt_out = h->dXt + (size_t)K; }
+            if (ib_next >= 0) { ff[ib_next].xb_out = h->dXb + (size_t)P * K; ff[ib_next].xt_out = h->dXt + (size_t)(P + 1) * K; }
+            HIPCHK(dalloc(&h->dIfsFast, (size_t)nif));
+            HIPCHK(hipMemcpyAsync(h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+        }
         HIPCHK(hipStreamSynchronize(st));
     }
     if (multi && !h->dSend) {
@@ -654,9 +731,15 @@ static int apply_dev(spike_handle h, const double *x, double *y)
         hipLaunchKernelGGL(k_gather_tips, dim3(h->P), dim3(64), 0, st, y, h->K, h->dChains, h->P, h->dTips, multi ? h->dSend : nullptr);
         HIPCHK(hipGetLastError());
         if (multi && (rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K))) return rc;
-        HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfs, st));
-        rc = run_pass(h, x, y, true);
-        if (rc) return rc;
+        if (h->spike_m > 0) {
+            // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
+            HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfsFast, st));
+            HIPCHK(launch_spike_correct(h->K, h->spike_m, h->dChains, h->P, h->dWf, h->dVf, h->dXb, h->dXt, y, st));
+        } else {
+            HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfs, st));
+            rc = run_pass(h, x, y, true);
+            if (rc) return rc;
+        }
     }
     return SPIKE_OK;
 }
@@ -908,7 +991,10 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
     o->nboost = h->nboost;
     o->factor_bytes = (int64_t)(2 * (size_t)h->ntiles * (size_t)h->cfg.tile_doubles() + (size_t)h->n) * 8;
-    o->iface_bytes = (int64_t)h->nif * 5 * (int64_t)h->K * h->K * 8;
+    o->iface_bytes = (int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) * (int64_t)h->K * h->K * 8;
+    o->passes = (h->variant == SPIKE_VARIANT_COUPLED && h->nif > 0 && h->spike_m == 0) ? 2 : 1;
+    o->spike_rows = h->spike_m;
+    o->spike_bytes = (int64_t)2 * h->spike_m * (int64_t)h->K * 8 * h->P;
     o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
     return SPIKE_OK;
 }
@@ -918,10 +1004,10 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
     if (!h || !buf || !len) return SPIKE_ERR_ARG;
     snprintf(buf, len,
              "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
-             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d\n",
+             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d\n",
              (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P,
              h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
-             (long long)h->nboost, h->setup_ms, h->nranks);
+             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m);
     return SPIKE_OK;
 }
 

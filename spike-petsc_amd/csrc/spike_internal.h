@@ -56,6 +56,8 @@ struct IfaceDesc {
     const double *CT;  // K*K, column-major C (coupling block of the lower partition) or null
     double *corr_bot;  // K doubles: B * x^(t)   (for the upper partition) or null
     double *corr_top;  // K doubles: C * x^(b)   (for the lower partition) or null
+    double *xb_out;    // K doubles: x^(b), bottom-tip solution of the upper partition, or null
+    double *xt_out;    // K doubles: x^(t), top-tip solution of the lower partition, or null
 };
 
 bool pick_cfg(int K, SweepCfg *cfg);
@@ -86,6 +88,14 @@ hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st);
 hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st);
+// stored (decayed) spikes: gather m rows of a spike column, measure what lies outside the window, and the
+// second "pass" of the coupled variant as a dense correction  x -= W x_b(prev) (top m rows), x -= V x_t(next)
+hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
+                               double *out, double *absmax_in, double *absmax_out, hipStream_t st);
+hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
+                               int *extent, hipStream_t st);
+hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
+                                const double *xb, const double *xt, double *x, hipStream_t st);
 
 // Krylov pieces (spike_krylov.hip)
 hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int tpr, const double *x,

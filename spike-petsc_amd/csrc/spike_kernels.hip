@@ -647,6 +647,10 @@ __global__ __launch_bounds__(256) void k_iface_apply(int K, const IfaceDesc *ifs
     s = iface_matvec(d.VT, v2, K, KA, nparts, a, part, redb);
     if (part == 0 && a < K) v1[a] = gb[a] - s;  // v1 = xb
     __syncthreads();
+    if (part == 0 && a < K) {
+        if (d.xb_out != nullptr) d.xb_out[a] = v1[a];
+        if (d.xt_out != nullptr) d.xt_out[a] = v2[a];
+    }
     if (d.corr_top != nullptr) {
         s = iface_matvec(d.CT, v1, K, KA, nparts, a, part, redb);
         if (part == 0 && a < K) d.corr_top[a] = s;
@@ -661,6 +665,103 @@ hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t 
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(256), (size_t)4 * K * sizeof(double), st, K, ifs);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// stored spikes.  For diagonally dominant bands the spikes V_j = A_j^{-1}[0;B_j], W_j = A_j^{-1}[C_j;0] decay
+// away from the interface; only their m significant rows are kept (column-major per partition:
+// out[(p*K + col)*m + r]), so the second pass of the coupled variant becomes a small dense correction.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_pos(double *addr, double v)
+{
+    atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// which = 0: W (rows [0,m) of each chain); which = 1: V (rows [nrows-m, nrows))
+__global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int which,
+                                                      int col, double *out, double *absmax_in, double *absmax_out)
+{
+    const int p = blockIdx.y;
+    const ChainDesc cd = chains[p];
+    double mi = 0.0, mo = 0.0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x) {
+        const double v = sol[cd.row0 + r];
+        const int w = which == 0 ? r : r - (cd.nrows - m);  // index inside the stored window
+        if (w >= 0 && w < m) {
+            out[((int64_t)p * K + col) * m + w] = v;
+            mi = fmax(mi, fabs(v));
+        } else mo = fmax(mo, fabs(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
+    if ((threadIdx.x & 63) == 0) { atomic_max_pos(absmax_in, mi); atomic_max_pos(absmax_out, mo); }
+}
+
+hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
+                               double *out, double *absmax_in, double *absmax_out, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spike_gather, dim3(8, nchains), dim3(256), 0, st, sol, K, m, chains, which, col, out, absmax_in,
+                       absmax_out);
+    return hipGetLastError();
+}
+
+// extent[0] = max over chains of the distance (in rows, from the interface) of the farthest entry with |v| > tol_abs
+__global__ __launch_bounds__(256) void k_spike_extent(const double *sol, const ChainDesc *chains, int which, double tol_abs,
+                                                      int *extent)
+{
+    const ChainDesc cd = chains[blockIdx.y];
+    int far = 0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x) {
+        const int dist = which == 0 ? r + 1 : cd.nrows - r;
+        if (fabs(sol[cd.row0 + r]) > tol_abs && dist > far) far = dist;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_down(far, o); far = t > far ? t : far; }
+    if ((threadIdx.x & 63) == 0 && far > 0) atomicMax(extent, far);
+}
+
+hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
+                               int *extent, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spike_extent, dim3(8, nchains), dim3(256), 0, st, sol, chains, which, tol_abs, extent);
+    return hipGetLastError();
+}
+
+// x[top m rows of chain p]    -= W_p x_b(p-1)   (xb slot p;   slot 0   = the previous rank's last partition)
+// x[bottom m rows of chain p] -= V_p x_t(p+1)   (xt slot p+2; slot P+1 = the next rank's first partition)
+// lane = row (coalesced column-major spike reads), K sequential FMAs per lane, tip vectors from LDS.
+__global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const ChainDesc *chains, const double *Wf,
+                                                       const double *Vf, const double *xb, const double *xt, double *x)
+{
+    extern __shared__ double tip[];
+    const int p = blockIdx.y, which = blockIdx.z;
+    const ChainDesc cd = chains[p];
+    const double *src = which == 0 ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
+    for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = src[c];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const double *S = (which == 0 ? Wf : Vf) + (int64_t)p * K * m + r;
+    double a0 = 0.0, a1 = 0.0;
+    int c = 0;
+    for (; c + 1 < K; c += 2) {
+        a0 = fma(S[(int64_t)c * m], tip[c], a0);
+        a1 = fma(S[(int64_t)(c + 1) * m], tip[c + 1], a1);
+    }
+    if (c < K) a0 = fma(S[(int64_t)c * m], tip[c], a0);
+    const int64_t row = cd.row0 + (which == 0 ? r : cd.nrows - m + r);
+    // when 2m > nrows the two windows overlap: the two contributions to a row must not race
+    if (2 * m > cd.nrows) atomicAdd(x + row, -(a0 + a1));
+    else x[row] -= a0 + a1;
+}
+
+hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
+                                const double *xb, const double *xt, double *x, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spike_correct, dim3((m + 255) / 256, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
+                       chains, Wf, Vf, xb, xt, x);
     return hipGetLastError();
 }
 

@@ -63,6 +63,50 @@ def test_apply_matches_oracle(spike, oracle, torch_cuda, N, K, P, delta):
         sp.close()
 
 
+@pytest.mark.parametrize("N,K,P", [(16384, 8, 8), (65536, 32, 16), (65536, 64, 8), (2 ** 17, 128, 8)])
+def test_coupled_one_pass_and_two_pass_agree(spike, oracle, torch_cuda, N, K, P):
+    """The coupled variant keeps the decayed part of the spikes when they are short and then needs ONE pass over the
+    factors (y = g - W x_b - V x_t); with spike_storage=off it re-solves (two passes).  Both must match the oracle."""
+    band = oracle.gen_band(N, K, delta=0.8)
+    f = oracle.gen_vec(N)
+    xo = oracle.Spike(band, P).apply(f, 1)
+    sp1 = spike.Spike(partitions=P).setup_band(band)
+    i1 = sp1.info()
+    assert i1.passes == 1 and 0 < i1.spike_rows <= N // P
+    assert _rel(sp1.apply(f), xo) <= TOL
+    sp2 = spike.Spike(partitions=P)
+    sp2.set_option("spike_storage", "off")
+    sp2.setup_band(band)
+    i2 = sp2.info()
+    assert i2.passes == 2 and i2.spike_rows == 0
+    assert _rel(sp2.apply(f), xo) <= TOL
+
+
+def test_spikes_that_do_not_decay(spike, oracle, torch_cuda):
+    """-1,2,-1 (not strictly dominant): the spikes decay only linearly, never below the drop level.  Narrow band:
+    the library keeps the FULL spikes (cheap at K=1) -> still one pass; wide band: it must fall back to re-solving.
+    Either way the result is the oracle's (same linear algebra)."""
+    N, P = 8192, 8
+    band = np.zeros((3, N)); band[0, 1:] = -1.0; band[1, :] = 2.0; band[2, :-1] = -1.0
+    f = oracle.gen_vec(N)
+    sp = spike.Spike(partitions=P).setup_band(band)
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-9
+    i = sp.info()
+    assert i.passes == 1 and i.spike_rows == N // P
+    K = 40
+    band = np.zeros((2 * K + 1, N))
+    for d in range(2 * K + 1):
+        band[d, :] = -1.0 / (1 + abs(d - K))
+    band[K, :] = 2.0 * np.sum(1.0 / (1 + np.arange(1, K + 1))) * 1.0000001
+    for d in range(2 * K + 1):          # zero the out-of-range corners
+        off = d - K
+        if off < 0: band[d, :-off] = 0.0
+        if off > 0: band[d, N - off:] = 0.0
+    sp = spike.Spike(partitions=P).setup_band(band)
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-8
+    assert sp.info().passes == 2 and sp.info().spike_rows == 0
+
+
 @pytest.mark.parametrize("N,K,P", [(8192, 8, 8), (16384, 64, 8), (32768, 128, 16)])
 def test_spike_tips_match_oracle(spike, oracle, torch_cuda, N, K, P):
     band = oracle.gen_band(N, K, delta=0.8)

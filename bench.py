@@ -9,9 +9,10 @@ banded system of SURVEY.md 8d (N = 4*2^20, K = 128, delta = 1.2, seed 12345), ge
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; the N-row system is split into N contiguous row blocks (strong scaling: total work
-fixed), each rank factors its own partitions, and the rank-boundary interface systems are assembled by an RCCL
-allgather inside the library (spike_comm_init).
+N > 1: one process per GPU.  SPIKE partitions are the independent units of this path, so by default every GPU
+gets the same number of rows (--n per GPU: "scaling": "weak"; the global system has --n * N rows); --scaling strong
+keeps the total at --n.  Each rank factors its own partitions; the rank-boundary interface systems are assembled by
+an RCCL allgather inside the library (spike_comm_init) -- the only data-path exchange (2K doubles per rank per apply).
 
 Algorithmic bytes per PCApply (SURVEY.md 8d / BASELINE.md 3):
     BYTES(N,K,p) = p*[(2K+1)*N*8 + 2*N*8] + (P-1)*[(2K)^2 + 4K]*8      p = 1 decoupled, p = 2 coupled
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--partitions", type=int, default=0, help="per GPU; 0 = auto")
     ap.add_argument("--variant", default="coupled", choices=["coupled", "decoupled"])
     ap.add_argument("--delta", type=float, default=1.2)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --n rows PER GPU, the partitions of every GPU are independent units; strong: --n rows in total")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ksp", action="store_true")
     ap.add_argument("--ksp-iters", type=int, default=30)
@@ -117,7 +120,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    N, K = args.n, args.k
+    K = args.k
+    N = args.n * world if args.scaling == "weak" else args.n
     # contiguous row blocks on 64-row boundaries
     nblk = (N + 63) // 64
     r0 = (nblk * rank // world) * 64
@@ -198,10 +202,10 @@ def main():
         out = {
             "metric": "PCApply GB/s", "value": gbps, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "banded N=%d half-bw=%d fp64, SPIKE %s, %d partitions (%d/GPU), delta=%.2f, seed 12345"
                                    % (N, K, args.variant, P_total, info.P_local, args.delta),
-                       "N": N, "K": K, "partitions": P_total, "variant": args.variant,
+                       "N": N, "N_per_gpu": n_local, "K": K, "partitions": P_total, "variant": args.variant,
                        "passes_over_factors": p, "rows_per_partition": n_local // info.P_local,
                        "stored_spike_rows": int(info.spike_rows)},
             "GBps_single_pass_bytes": gbps_1,

@@ -433,6 +433,23 @@ __global__ void k_gather_tips(const double *g, int K, const ChainDesc *chains, i
     }
 }
 
+// band slots whose column falls outside [0, n_global) are "ignored" by the ABI: zero them in the library's copy so
+// that kernels may multiply them by (zero) halo values without masking
+__global__ void k_zero_corners(double *band, int64_t ld, int K, int64_t n_global, int64_t row0, int64_t n)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // over 2K candidate rows x (2K+1) diagonals
+    const int nd = 2 * K + 1;
+    if (t >= (int64_t)2 * K * nd) return;
+    const int d = (int)(t % nd);
+    const int64_t q = t / nd;
+    const int64_t gi = q < K ? q : n_global - 2 * K + q;  // first K and last K global rows
+    if (gi < 0 || gi >= n_global) return;
+    if (q >= K && gi < K) return;  // tiny systems: already covered by the first range
+    const int64_t c = gi + d - K, i = gi - row0;
+    if (i < 0 || i >= n) return;
+    if (c < 0 || c >= n_global) band[(int64_t)d * ld + i] = 0.0;
+}
+
 __global__ void k_copy_halo(const double *x, int64_t n, int K, double *send)
 {
     for (int a = threadIdx.x; a < K; a += blockDim.x) {
@@ -481,6 +498,11 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         h->ownA = true; h->ldA = n;
         HIPCHK(hipMemcpy2DAsync(h->dA, n * sizeof(double), band, ld * sizeof(double), n * sizeof(double), nd,
                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (K > 0) {
+            const int64_t tot = (int64_t)2 * K * nd;
+            hipLaunchKernelGGL(k_zero_corners, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->dA, h->ldA, K, n_global, row0, n);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(dalloc(&h->dChains, (size_t)P));
     HIPCHK(dalloc(&h->dGroups, h->groups.size()));
@@ -844,7 +866,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
         HIPCHK(dalloc(&h->dCoef, (size_t)m + 2));
         h->gm_restart = m;
     }
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m), hcol(m + 2);
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m + 2), hcol(m + 2);
     int it = 0, rc = 0;
     bool conv = false;
     double r0 = -1.0, rn = 0.0;
@@ -876,23 +898,34 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
             double *vj = h->dV + (size_t)j * n, *vn = h->dV + (size_t)(j + 1) * n;
             if ((rc = matvec_dev(h, vj, h->dW))) return rc;
             if ((rc = precond(h->dW, vn))) return rc;
-            // classical Gram-Schmidt with one re-orthogonalisation (two fused passes instead of j+1 dots)
+            // classical Gram-Schmidt; ONE fused multi-dot pass also returns |vn|^2, so the norm of the orthogonalised
+            // vector comes from Pythagoras without a second reduction.  A second pass (and an explicit norm) is made
+            // only when cancellation is severe (DGKS criterion), like PETSc's -ksp_gmres_cgs_refinement_type ifneeded.
             for (int i = 0; i <= j; ++i) hcol[i] = 0.0;
+            double hn = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
-                HIPCHK(launch_dots(h->dV, n, j + 1, vn, n, h->dDots, st));
-                if ((rc = dist_sum(h, h->dDots, j + 1))) return rc;
+                // vn is stored right behind V_j, so "j+2 vectors" = V_0..V_j and vn itself
+                HIPCHK(launch_dots(h->dV, n, j + 2, vn, n, h->dDots, st));
+                if ((rc = dist_sum(h, h->dDots, j + 2))) return rc;
                 HIPCHK(launch_axpys(h->dV, n, j + 1, h->dDots, vn, n, -1.0, st));
-                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 1), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 2), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                for (int i = 0; i <= j; ++i) hcol[i] += yv[i];
+                double s2 = 0.0;
+                for (int i = 0; i <= j; ++i) { hcol[i] += yv[i]; s2 += yv[i] * yv[i]; }
+                const double before = yv[j + 1], after = before - s2;
+                if (after > 0.5 * before || pass == 1) {
+                    if (after > 0.25 * before) { hn = std::sqrt(after); break; }
+                    // heavy cancellation even after refinement: take the norm explicitly
+                    HIPCHK(launch_dots(vn, n, 1, vn, n, h->dDots, st));
+                    if ((rc = dist_sum(h, h->dDots, 1))) return rc;
+                    double hh = 0.0;
+                    HIPCHK(hipMemcpyAsync(&hh, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    hn = std::sqrt(hh);
+                    break;
+                }
             }
-            HIPCHK(launch_dots(vn, n, 1, vn, n, h->dDots, st));
-            if ((rc = dist_sum(h, h->dDots, 1))) return rc;
-            double hh = 0.0;
-            HIPCHK(hipMemcpyAsync(&hh, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            const double hn = std::sqrt(hh);
-            if (hn != 0.0) HIPCHK(launch_scale_copy(vn, h->dDots, 1, vn, n, st));
+            if (hn != 0.0) HIPCHK(launch_scale_value(vn, 1.0 / hn, n, st));
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
             H[(size_t)(j + 1) * m + j] = hn;
             for (int i = 0; i < j; ++i) {

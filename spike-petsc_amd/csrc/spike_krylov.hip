@@ -99,6 +99,20 @@ hipError_t launch_scale_copy(const double *w, const double *scal_dev, int invert
     return hipGetLastError();
 }
 
+__global__ void k_scale_value(double *w, double s, int64_t n)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) w[r] *= s;
+}
+
+hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st)
+{
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_scale_value, dim3(grid), dim3(256), 0, st, w, s, n);
+    return hipGetLastError();
+}
+
 __global__ void k_residual(const double *b, const double *ax, double *r, int64_t n)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -389,10 +389,15 @@ static int build_chains(spike_handle h)
 }
 
 // one forward+backward pass over all chains: out = blockdiag(A_p)^{-1} (in - corrections)
-static int run_pass(spike_handle h, const double *in, double *out, bool with_corr)
+struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes are computed only where they live)
+    const ChainDesc *chains = nullptr;
+    const GroupDesc *groupsF = nullptr, *groupsB = nullptr;
+};
+
+static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr)
 {
     SweepArgs a;
-    a.groups = h->dGroups; a.chains = h->dChains; a.nchains = h->P; a.K = h->K;
+    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = h->P; a.K = h->K;
     a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
     a.corr_top = with_corr ? h->dCorrTop : nullptr;
     a.corr_bot = with_corr ? h->dCorrBot : nullptr;
@@ -412,6 +417,7 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream));
     rec(false);
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
+    if (sub) a.groups = sub->groupsB;
     rec(true);
     HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream));
     rec(false);
@@ -603,11 +609,51 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(dalloc(&h->dWf, (size_t)P * K * m));
             HIPCHK(dalloc(&h->dVf, (size_t)P * K * m));
         }
+        // The spikes vanish beyond m rows, so the 2K solves only need the row blocks next to the interfaces:
+        // the top nb blocks of every chain for W, the bottom nb blocks for V (exact on the forward sweep, and the
+        // backward sweep starts where the solution is already below the drop level).
+        SubChains subTop, subBot;
+        ChainDesc *dSubC[2] = {nullptr, nullptr};
+        GroupDesc *dSubG[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool partial = false;
+        if (m > 0 && cfg.CPW() == 1) {
+            const int R = cfg.R;
+            int nsmin = h->chains[0].nsteps;
+            for (int p = 1; p < P; ++p) nsmin = std::min<int>(nsmin, h->chains[p].nsteps);
+            const int nb = (m + K + R - 1) / R + 1;
+            if (nb < nsmin) {
+                partial = true;
+                std::vector<ChainDesc> ct(P), cb(P);
+                std::vector<GroupDesc> gtF(P), gtB(P), gbF(P), gbB(P);
+                for (int p = 0; p < P; ++p) {
+                    const ChainDesc &c = h->chains[p];
+                    const GroupDesc &g = h->groups[p];
+                    const int skip = c.nsteps - nb;
+                    ct[p].row0 = c.row0; ct[p].nrows = std::min<int>(c.nrows, nb * R); ct[p].nsteps = nb;
+                    gtF[p] = g; gtF[p].maxsteps = nb;
+                    gtB[p] = g; gtB[p].maxsteps = nb; gtB[p].tile0 = g.tile0 + skip;
+                    cb[p].row0 = c.row0 + (int64_t)skip * R; cb[p].nrows = c.nrows - skip * R; cb[p].nsteps = nb;
+                    gbF[p] = g; gbF[p].maxsteps = nb; gbF[p].tile0 = g.tile0 + skip;
+                    gbB[p] = g; gbB[p].maxsteps = nb;
+                }
+                for (int i = 0; i < 2; ++i) HIPCHK(dalloc(&dSubC[i], (size_t)P));
+                for (int i = 0; i < 4; ++i) HIPCHK(dalloc(&dSubG[i], (size_t)P));
+                HIPCHK(hipMemcpyAsync(dSubC[0], ct.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(dSubC[1], cb.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(dSubG[0], gtF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(dSubG[1], gtB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(dSubG[2], gbF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(dSubG[3], gbB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+                subTop.chains = dSubC[0]; subTop.groupsF = dSubG[0]; subTop.groupsB = dSubG[1];
+                subBot.chains = dSubC[1]; subBot.groupsF = dSubG[2]; subBot.groupsB = dSubG[3];
+            }
+        }
         for (int which = 0; which < 2; ++which) {
             HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
             for (int col = 0; col < K; ++col) {
                 HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
-                rc = run_pass(h, rhs, sol, false);
+                rc = run_pass(h, rhs, sol, false, partial ? (which == 0 ? &subTop : &subBot) : nullptr);
                 if (rc) return rc;
                 HIPCHK(launch_tip_gather(sol, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st));
                 if (m > 0) HIPCHK(launch_spike_gather(sol, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st));
@@ -618,7 +664,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             double stat[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(stat, dStat, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            // anything of weight left outside the window?  then the spikes do not decay: keep the re-solve variant
+            // anything of weight left at the far edge of the window?  then the spikes do not decay: keep the re-solve variant
             if (m < nmin && stat[1] > 1e3 * h->spike_tol * stat[0]) {
                 (void)hipFree(h->dWf); (void)hipFree(h->dVf);
                 h->dWf = h->dVf = nullptr;
@@ -627,6 +673,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         }
         h->spike_m = m;
         HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < 2; ++i) if (dSubC[i]) HIPCHK(hipFree(dSubC[i]));
+        for (int i = 0; i < 4; ++i) if (dSubG[i]) HIPCHK(hipFree(dSubG[i]));
         HIPCHK(hipFree(sol));
         HIPCHK(hipFree(dStat));
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 0, h->dCT, st));

@@ -700,31 +700,32 @@ __device__ __forceinline__ void atomic_max_pos(double *addr, double v)
     atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
 }
 
-// which = 0: W (rows [0,m) of each chain); which = 1: V (rows [nrows-m, nrows))
+// which = 0: W (rows [0,m) of each chain); which = 1: V (rows [nrows-m, nrows)).  absmax_in = peak magnitude inside the
+// window, absmax_edge = peak over the 32 window rows farthest from the interface (must be ~0 for a decayed spike).
 __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int which,
-                                                      int col, double *out, double *absmax_in, double *absmax_out)
+                                                      int col, double *out, double *absmax_in, double *absmax_edge)
 {
     const int p = blockIdx.y;
     const ChainDesc cd = chains[p];
     double mi = 0.0, mo = 0.0;
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x) {
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < m; w += gridDim.x * blockDim.x) {
+        const int r = which == 0 ? w : cd.nrows - m + w;
         const double v = sol[cd.row0 + r];
-        const int w = which == 0 ? r : r - (cd.nrows - m);  // index inside the stored window
-        if (w >= 0 && w < m) {
-            out[((int64_t)p * K + col) * m + w] = v;
-            mi = fmax(mi, fabs(v));
-        } else mo = fmax(mo, fabs(v));
+        out[((int64_t)p * K + col) * m + w] = v;
+        mi = fmax(mi, fabs(v));
+        const int dist = which == 0 ? w : m - 1 - w;  // distance from the interface, in rows
+        if (dist >= m - 32) mo = fmax(mo, fabs(v));
     }
     for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
-    if ((threadIdx.x & 63) == 0) { atomic_max_pos(absmax_in, mi); atomic_max_pos(absmax_out, mo); }
+    if ((threadIdx.x & 63) == 0) { atomic_max_pos(absmax_in, mi); atomic_max_pos(absmax_edge, mo); }
 }
 
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
                                double *out, double *absmax_in, double *absmax_out, hipStream_t st)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spike_gather, dim3(8, nchains), dim3(256), 0, st, sol, K, m, chains, which, col, out, absmax_in,
-                       absmax_out);
+    hipLaunchKernelGGL(k_spike_gather, dim3((m + 255) / 256 < 8 ? (m + 255) / 256 : 8, nchains), dim3(256), 0, st, sol, K, m,
+                       chains, which, col, out, absmax_in, absmax_out);
     return hipGetLastError();
 }
 

@@ -239,7 +239,286 @@ __global__ __launch_bounds__(256) void k_factor(double *lu, int64_t ld, int K, c
     if (tid == 0 && nb) atomicAdd(nboost, nb);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_factor_mfma: blocked right-looking banded LU (block = 16) for K padded to 16*KB, KB in {1,2,4,8,16}.
+// The trailing K x K window of a partition lives in MFMA accumulator registers (KB x KB tiles of 16 x 16, a wave owns
+// RPW tile rows); the panels of the current block step go through LDS; the rank-16 update of the window is
+// v_mfma_f64_16x16x4_f64 (4 per tile).  The window slides diagonally by one tile per step: tiles are addressed by
+// SLOT (block index mod KB), so nothing moves -- the slots of the finished pivot row/column are refilled with the
+// tiles that enter the window.  Compute-bound part of setup: 2*N*K^2 flop (1.4e11 at N = 4M, K = 128).
+// f64 MFMA lane maps (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// C/D: col = l&15, row = (l>>4) + 4*reg.
+// ------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int LDT = 17;            // LDS tile row stride (doubles), padded against bank conflicts
+constexpr int TS = 16 * LDT;       // LDS tile size
+
+// One block step's panel work, shared by both factor kernels: LU of the 16 x 16 diagonal tile (no pivoting, pivot
+// boosting), the two panel solves, and the write-back of the finished block row / column to the LU band.
+// Called by all threads after the panel tiles are in LDS and a barrier; returns after the write-back was issued
+// (the caller's next barrier orders it).
+template <int KB, int NT>
+__device__ __forceinline__ void panel_phase(double *Pd, double *Pc, double *Pr, int s, int np, int64_t rs, int K, int64_t ld,
+                                            double *lu, double boost, unsigned long long &nb, int tid, int lane, int w)
+{
+    // ---- 16 x 16 diagonal block: LU without pivoting, pivot boosting (one wave, in LDS)
+    if (w == 0) {
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        for (int k = 0; k < 16; ++k) {
+            double piv = Pd[k * LDT + k];
+            const bool real_row = 16 * s + k < np;
+            if (real_row && fabs(piv) < boost) {
+                piv = (piv < 0.0) ? -boost : boost;
+                if (lane == 0) ++nb;
+            }
+            double l = 0.0;
+            if (r > k) l = Pd[r * LDT + k] / piv;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) Pd[k * LDT + k] = piv;
+            if (r > k) {
+                if ((lane & 3) == 0) Pd[r * LDT + k] = l;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (c0 + cc > k) Pd[r * LDT + c0 + cc] -= l * Pd[k * LDT + c0 + cc];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    // ---- panels: L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
+    for (int t = tid; t < 2 * 16 * KB; t += NT) {
+        const int which = t / (16 * KB), idx = t % (16 * KB), tile = idx >> 4, line = idx & 15;
+        double x[16];
+        if (which == 0) {
+            double *T = Pc + tile * TS + line * LDT;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = T[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) v -= x[k] * Pd[k * LDT + c];
+                x[c] = v / Pd[c * LDT + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) T[c] = x[c];
+        } else {
+            double *T = Pr + tile * TS + line;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = T[r * LDT];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double v = x[r];
+#pragma unroll
+                for (int k = 0; k < r; ++k) v -= Pd[r * LDT + k] * x[k];
+                x[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r * LDT] = x[r];
+        }
+    }
+    __syncthreads();
+    // ---- write the finished block row / block column back (diagonal-major LU band)
+    for (int t = tid; t < (2 * KB + 1) * 256; t += NT) {
+        const int tile = t >> 8, row = (t >> 4) & 15, col = t & 15;
+        int rb, cb;
+        const double *T;
+        if (tile == 0) { rb = s; cb = s; T = Pd; }
+        else if (tile <= KB) { rb = s + tile; cb = s; T = Pc + (tile - 1) * TS; }
+        else { rb = s; cb = s + tile - KB; T = Pr + (tile - KB - 1) * TS; }
+        const int r = 16 * rb + row, c = 16 * cb + col;
+        const int d = c - r + K;
+        if (r < np && c < np && d >= 0 && d <= 2 * K) lu[(int64_t)d * ld + rs + r] = T[row * LDT + col];
+    }
+}
+
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void k_factor_mfma(double *lu, int64_t ld, int K, const ChainDesc *chains, double boost,
+                                                         unsigned long long *nboost)
+{
+    constexpr int RPW = KB / NW;
+    constexpr int NT = NW * 64;
+    extern __shared__ double lds[];
+    double *Pd = lds, *Pc = lds + TS, *Pr = lds + TS + KB * TS;
+    const ChainDesc cd = chains[blockIdx.x];
+    const int64_t rs = cd.row0;
+    const int np = cd.nrows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = (np + 15) / 16;
+    unsigned long long nb = 0;
+
+    auto ldA = [&](int rb, int cb, int row, int col) -> double {
+        const int r = 16 * rb + row, c = 16 * cb + col;  // partition-local
+        if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;  // identity padding past the partition end
+        const int d = c - r + K;
+        if (d < 0 || d > 2 * K) return 0.0;
+        return lu[(int64_t)d * ld + rs + r];
+    };
+    auto load_tile = [&](v4d &t, int rb, int cb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
+    };
+    auto store_tile = [&](const v4d &t, double *dst) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
+    };
+
+    v4d acc[RPW][KB];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) load_tile(acc[rr][b], rr * NW + w, b);
+
+    for (int s = 0; s < nblk; ++s) {
+        const int as = s % KB;
+        // pivot row / column tiles: registers -> LDS panels; then refill those slots with the entering tiles
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int a = rr * NW + w;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                if (a == as) {
+                    const int J = (b - as + KB) % KB;  // tile (s, s+J)
+                    store_tile(acc[rr][b], J == 0 ? Pd : Pr + (J - 1) * TS);
+                    const int Jn = (b - as - 1 + KB) % KB + 1;  // new tile (s+KB, s+Jn)
+                    load_tile(acc[rr][b], s + KB, s + Jn);
+                } else if (b == as) {
+                    const int I = (a - as + KB) % KB;  // tile (s+I, s), I in 1..KB-1
+                    store_tile(acc[rr][b], Pc + (I - 1) * TS);
+                    load_tile(acc[rr][b], s + I, s + KB);  // new tile (s+I, s+KB)
+                }
+            }
+        }
+        // the two panel tiles that were not in the window yet: (s+KB, s) and (s, s+KB)
+        for (int t = tid; t < 256; t += NT) {
+            const int row = t >> 4, col = t & 15;
+            Pc[(KB - 1) * TS + row * LDT + col] = ldA(s + KB, s, row, col);
+            Pr[(KB - 1) * TS + row * LDT + col] = ldA(s, s + KB, row, col);
+        }
+        __syncthreads();
+        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, K, ld, lu, boost, nb, tid, lane, w);
+        // ---- trailing update: tile(s+I, s+J) -= L21[I] * U12[J]   (4 x v_mfma_f64_16x16x4_f64 per tile)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int a = rr * NW + w;
+            const int I = (a - as - 1 + KB) % KB + 1;
+            const double *Lp = Pc + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
+            double la[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) la[q] = -Lp[4 * q];
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int J = (b - as - 1 + KB) % KB + 1;
+                const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[rr][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Up[4 * q * LDT], acc[rr][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
+}
+
+// Same algorithm with the trailing window left in global memory (L2 / Infinity Cache resident) and updated in place:
+// used when the K x K window (512 KiB at K = 256) does not fit the register file of one CU.
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int64_t ld, int K, const ChainDesc *chains,
+                                                                 double boost, unsigned long long *nboost)
+{
+    constexpr int NT = NW * 64;
+    extern __shared__ double lds[];
+    double *Pd = lds, *Pc = lds + TS, *Pr = lds + TS + KB * TS;
+    const ChainDesc cd = chains[blockIdx.x];
+    const int64_t rs = cd.row0;
+    const int np = cd.nrows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = (np + 15) / 16;
+    unsigned long long nb = 0;
+    auto ldA = [&](int rb, int cb, int row, int col) -> double {
+        const int r = 16 * rb + row, c = 16 * cb + col;
+        if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;
+        const int d = c - r + K;
+        if (d < 0 || d > 2 * K) return 0.0;
+        return lu[(int64_t)d * ld + rs + r];
+    };
+    for (int s = 0; s < nblk; ++s) {
+        for (int t = tid; t < (2 * KB + 1) * 256; t += NT) {
+            const int tile = t >> 8, row = (t >> 4) & 15, col = t & 15;
+            if (tile == 0) Pd[row * LDT + col] = ldA(s, s, row, col);
+            else if (tile <= KB) Pc[(tile - 1) * TS + row * LDT + col] = ldA(s + tile, s, row, col);
+            else Pr[(tile - KB - 1) * TS + row * LDT + col] = ldA(s, s + tile - KB, row, col);
+        }
+        __syncthreads();
+        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, K, ld, lu, boost, nb, tid, lane, w);
+        for (int t = w; t < KB * KB; t += NW) {
+            const int I = t / KB + 1, J = t % KB + 1;
+            if (16 * (s + I) >= np || 16 * (s + J) >= np) continue;
+            v4d acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = ldA(s + I, s + J, (lane >> 4) + 4 * q, lane & 15);
+            const double *Lp = Pc + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
+            const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[4 * q], Up[4 * q * LDT], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * (s + I) + (lane >> 4) + 4 * q, c = 16 * (s + J) + (lane & 15);
+                const int d = c - r + K;
+                if (r < np && c < np && d >= 0 && d <= 2 * K) lu[(int64_t)d * ld + rs + r] = acc[q];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
+}
+
+template <int KB, int NW>
+static hipError_t launch_factor_mfma_inplace_t(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains,
+                                               double boost, unsigned long long *nboost, hipStream_t st)
+{
+    const size_t shm = (size_t)(2 * KB + 1) * TS * sizeof(double);
+    if (shm > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma_inplace<KB, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_factor_mfma_inplace<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lu, ld, K, chains, boost, nboost);
+    return hipGetLastError();
+}
+
+template <int KB, int NW>
+static hipError_t launch_factor_mfma_t(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+                                       unsigned long long *nboost, hipStream_t st)
+{
+    const size_t shm = (size_t)(2 * KB + 1) * TS * sizeof(double);
+    if (shm > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma<KB, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_factor_mfma<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lu, ld, K, chains, boost, nboost);
+    return hipGetLastError();
+}
+
+hipError_t launch_factor_generic(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+                                 unsigned long long *nboost, hipStream_t st);
+
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+                         unsigned long long *nboost, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    if (K <= 8) return launch_factor_generic(lu, ld, K, chains, nchains, boost, nboost, st);
+    if (K <= 16) return launch_factor_mfma_t<1, 1>(lu, ld, K, chains, nchains, boost, nboost, st);
+    if (K <= 32) return launch_factor_mfma_t<2, 2>(lu, ld, K, chains, nchains, boost, nboost, st);
+    if (K <= 64) return launch_factor_mfma_t<4, 4>(lu, ld, K, chains, nchains, boost, nboost, st);
+    if (K <= 128) return launch_factor_mfma_t<8, 4>(lu, ld, K, chains, nchains, boost, nboost, st);
+    return launch_factor_mfma_inplace_t<16, 8>(lu, ld, K, chains, nchains, boost, nboost, st);
+}
+
+hipError_t launch_factor_generic(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st)
 {
     if (nchains <= 0) return hipSuccess;

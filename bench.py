@@ -179,6 +179,8 @@ def main():
     pass_ms = sweep_ms / n_pass if sweep_launches else float("nan")
     achieved = pass_bytes / (pass_ms * 1e-3) / 1e9 if sweep_launches else float("nan")
 
+    read_ceiling = sp.measure_read_bw(10)   # pure read stream over the same factors (GB/s), this device, this run
+
     # Krylov: fixed number of left-preconditioned GMRES(30) iterations (rtol=0 so it never stops early)
     ksp = None
     if not args.no_ksp:
@@ -215,7 +217,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(N, K, world),
-                         "alg_bytes_per_pass": pass_bytes, "pass_ms": pass_ms},
+                         "alg_bytes_per_pass": pass_bytes, "pass_ms": pass_ms,
+                         "measured_read_ceiling_GBps": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling},
         }
         if not args.no_cpu and world == 1:
             try:

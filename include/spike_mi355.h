@@ -165,6 +165,10 @@ int spike_get_tips(spike_handle h, double *Vb, double *Wt);
  * HIP events recorded on the handle's stream (valid after spike_set_option(h,"profile","1")) */
 int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches);
 
+/* measurement hook: GB/s of a pure read stream over the handle's packed factors (same 16-byte-per-lane
+ * non-temporal access shape as the sweeps), i.e. the read ceiling this device delivers                     */
+int spike_measure_read_bw(spike_handle h, int reps, double *gbps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "spike_comm_unique_id", "spike_comm_init", "spike_comm_init_local", "spike_setup_band", "spike_setup_csr", "spike_apply", "spike_gmres",
     "spike_band_matvec", "spike_gen_band", "spike_get_info", "spike_view", "spike_get_tips", "spike_last_sweep_ms",
     "spike_set_operator_csr", "spike_clear_operator", "spike_dev_malloc", "spike_dev_free", "spike_dev_upload",
-    "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band",
+    "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band", "spike_measure_read_bw",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
     L.spike_view.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.spike_get_tips.argtypes = [vp, dptr, dptr]
     L.spike_last_sweep_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.spike_measure_read_bw.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.spike_csr_band_k.argtypes = [i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]
     L.spike_csr_to_band.argtypes = [i64, iptr, iptr, dptr, C.c_int, dptr, i64]
@@ -242,6 +243,11 @@ class Spike:
         nl = C.c_int(0)
         self._chk(self.L.spike_last_sweep_ms(self.h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def measure_read_bw(self, reps=10):
+        g = C.c_double(0)
+        self._chk(self.L.spike_measure_read_bw(self.h, reps, C.byref(g)))
+        return g.value
 
     def reset(self):
         self._chk(self.L.spike_reset(self.h))

@@ -888,6 +888,28 @@ extern "C" int spike_gen_band(void *stream, int64_t n_global, int K, uint64_t se
     return e == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
 }
 
+// Read-bandwidth ceiling of this device for the sweeps' access shape: streams the handle's packed L factors `reps`
+// times with a pure read kernel and returns GB/s (HIP events on the handle's stream).
+extern "C" int spike_measure_read_bw(spike_handle h, int reps, double *gbps)
+{
+    if (!h || !gbps || reps < 1) return SPIKE_ERR_ARG;
+    if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_measure_read_bw needs a setup");
+    const int64_t nd = h->ntiles * h->cfg.tile_doubles();
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(launch_read_bw(h->dLt, nd, h->dY, h->stream));  // warm-up
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(launch_read_bw(r & 1 ? h->dUt : h->dLt, nd, h->dY, h->stream));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const int64_t per = ((nd / 2) / (256 * 8)) & ~(int64_t)2047;  // what k_read_bw really reads per block (in double2)
+    *gbps = (double)per * (256 * 8) * 16.0 * reps / (ms * 1e-3) / 1e9;
+    return SPIKE_OK;
+}
+
 // ---- GMRES -----------------------------------------------------------------------------------------------------
 static int dist_sum(spike_handle h, double *dvals, int count)
 {

@@ -97,6 +97,8 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st);
 
+hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hipStream_t st);
+
 // Krylov pieces (spike_krylov.hip)
 hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int tpr, const double *x,
                              double *y, hipStream_t st);

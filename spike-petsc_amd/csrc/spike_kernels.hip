@@ -22,6 +22,15 @@ namespace spike {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// Lanes of ONE wave exchange values through LDS without a workgroup barrier (the hardware executes a wave's DS
+// instructions in order).  The compiler, however, reasons per thread and may sink a store below loads it proves not to
+// alias for that thread; this fence pins the program order of the LDS accesses at wavefront scope (no instruction).
+#define WAVE_LDS_FENCE()                                          \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------
 // configuration
 // ------------------------------------------------------------------------------------------
@@ -65,7 +74,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     constexpr int NWB = ((R - 2) / DPW + 1) < NW ? ((R - 2) / DPW + 1) : NW;  // waves that own in-block entries
     constexpr int64_t TILE2 = (int64_t)NW * NLD * 64;                         // tile size in double2
 
-    __shared__ double W[CPW][WS];       // circular window of finished values, per chain
+    __shared__ double W[CPW][2 * WS];   // circular window of finished values, per chain, stored TWICE (at i and
+                                        // i + WS) so that a block's reads never wrap: one base address + immediates
     __shared__ double W2[CPW][KP + R];  // [KP zeros][R block-local intermediates]
     __shared__ double red[NW][64];
     __shared__ double red2[NWB][64];
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     if (valid) cd = a.chains[p];
     const GroupDesc gd = a.groups[blockIdx.x];
 
-    for (int t = threadIdx.x; t < CPW * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
+    for (int t = threadIdx.x; t < CPW * 2 * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
     for (int t = threadIdx.x; t < CPW * (KP + R); t += NW * 64) (&W2[0][0])[t] = 0.0;
     __syncthreads();
 
@@ -113,13 +123,18 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         }
         // ---- phase A: far part (columns of earlier blocks).  The block's own window slots are
         // zero while it runs, so in-block entries (stored in the same tile) contribute nothing.
-        W[c][(pos + lr) & (WS - 1)] = 0.0;
+        const int slot = (pos + lr) & (WS - 1);           // where this lane's value of the current block lives
+        double *wr = &W[c][slot];
+        wr[0] = 0.0;
+        wr[WS] = 0.0;
+        WAVE_LDS_FENCE();
+        // pos is a multiple of R and WS a multiple of R, so (pos & (WS-1)) + WS + lr - d stays inside [R, 2*WS)
+        const double *wp = &W[c][(pos & (WS - 1)) + WS + lr - KP - w * DPW];
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int d0 = w * DPW + 1 + 2 * i;
-            acc0 = fma(t[i].x, W[c][(pos + lr - d0) & (WS - 1)], acc0);
-            acc1 = fma(t[i].y, W[c][(pos + lr - d0 - 1) & (WS - 1)], acc1);
+            acc0 = fma(t[i].x, wp[KP - 1 - 2 * i], acc0);   // d = w*DPW + 1 + 2i
+            acc1 = fma(t[i].y, wp[KP - 2 - 2 * i], acc1);   // d + 1
         }
         double acc = acc0 + acc1;
         if (NW > 1) {
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         const double tt = fv - acc;
         // ---- phase B: in-block part through the inverted diagonal block (entries stored negated)
         W2[c][KP + lr] = tt;
+        WAVE_LDS_FENCE();
         double g = tt;
         if (w < NWB) {
             double b0 = 0.0, b1 = 0.0;
@@ -151,7 +167,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
             for (int ww = 0; ww < NWB; ++ww) s2 += red2[ww][lane];
             g = tt - s2;
         }
-        W[c][(pos + lr) & (WS - 1)] = g;
+        WAVE_LDS_FENCE();  // all in-block reads of this step precede the overwrite of the block's slots
+        wr[0] = g;
+        wr[WS] = g;
+        WAVE_LDS_FENCE();
         if (act && w == 0) a.out[gi] = REV ? g : g * dv;
         pos += R;
     };
@@ -996,7 +1015,11 @@ __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, 
         if (dist >= m - 32) mo = fmax(mo, fabs(v));
     }
     for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
-    if ((threadIdx.x & 63) == 0) { atomic_max_pos(absmax_in, mi); atomic_max_pos(absmax_edge, mo); }
+    // thousands of waves share two words: only touch them when the running maximum would actually grow
+    if ((threadIdx.x & 63) == 0) {
+        if (mi > __hip_atomic_load(absmax_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(absmax_in, mi);
+        if (mo > __hip_atomic_load(absmax_edge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(absmax_edge, mo);
+    }
 }
 
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
@@ -1064,6 +1087,35 @@ hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchai
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_spike_correct, dim3((m + 255) / 256, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
                        chains, Wf, Vf, xb, xt, x);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// read-bandwidth ceiling: the same access shape as a sweep's tile stream (16 B per lane, 1 KiB per wave
+// instruction, non-temporal, every byte read once) with nothing else in the way.  bench.py reports it beside
+// the spec peak so that roofline.frac can be read against what this chip delivers for a pure read stream.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_read_bw(const d2 *src, int64_t n2, double *sink)
+{
+    // every block streams one contiguous region front to back (as a chain does), 8 x 16-byte loads in flight per lane
+    const int64_t per = (n2 / gridDim.x) & ~(int64_t)2047;
+    const d2 *p = src + blockIdx.x * per + threadIdx.x;
+    d2 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = d2{0, 0};
+    for (int64_t i = 0; i + 2048 <= per; i += 2048) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += __builtin_nontemporal_load(p + i + k * 256);
+    }
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += a[k].x + a[k].y;
+    if (t == 1.2345e300) sink[0] = t;  // keeps the loads alive, never true for finite data
+}
+
+hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<const d2 *>(src), ndoubles / 2, sink);
     return hipGetLastError();
 }
 

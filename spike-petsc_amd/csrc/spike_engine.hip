@@ -228,6 +228,30 @@ static int coll_allreduce(spike_handle h, double *buf, size_t count, int op)
     return SPIKE_OK;
 }
 
+// Scratch device buffers of one setup call: released on every exit path (early error returns included).
+struct TmpPool {
+    std::vector<void *> ptrs;
+    template <class T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        hipError_t e = dalloc(p, count);
+        if (e == hipSuccess) ptrs.push_back((void *)*p);
+        return e;
+    }
+    template <class T>
+    void release(T *&p)  // free one buffer early (the LU scratch is as large as the band)
+    {
+        for (auto &q : ptrs)
+            if (q == (void *)p) { (void)hipFree(q); q = nullptr; }
+        p = nullptr;
+    }
+    ~TmpPool()
+    {
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+};
+
 static void free_factors(spike_handle h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
@@ -487,6 +511,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     if (!pick_cfg(K, &cfg)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..256)", K);
     (void)hipStreamSynchronize(h->stream);
     free_factors(h);
+    TmpPool tmp;
     const auto t_start = std::chrono::steady_clock::now();
     h->cfg = cfg;
     h->n_global = n_global; h->row0 = row0; h->n = n; h->K = K;
@@ -517,7 +542,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
 
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
     double *dScal = nullptr;
-    HIPCHK(dalloc(&dScal, 2));
+    HIPCHK(tmp.alloc(&dScal, 2));
     HIPCHK(launch_absmax_diag(h->dA, h->ldA, K, n, dScal, st));
     if ((rc = coll_allreduce(h, dScal, 1, NCCL_MAX))) return rc;
     double dmax = 0.0;
@@ -527,7 +552,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
 
     // LU (scratch copy), then pack into sweep tiles
     double *dLU = nullptr;
-    HIPCHK(dalloc(&dLU, (size_t)nd * n));
+    HIPCHK(tmp.alloc(&dLU, (size_t)nd * n));
     HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
@@ -545,8 +570,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->nboost = (int64_t)nb;
-    HIPCHK(hipFree(dLU));
-    HIPCHK(hipFree(dScal));
+    tmp.release(dLU);
+    tmp.release(dScal);
 
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
     const bool multi = h->nranks > 1;
@@ -570,13 +595,13 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(hipMemsetAsync(h->dVb, 0, sizeof(double) * P * kk, st));
         double *rhs = h->dTmp;
         double *sol = nullptr;
-        HIPCHK(dalloc(&sol, (size_t)n));
+        HIPCHK(tmp.alloc(&sol, (size_t)n));
         const bool keep_prof = h->profile;
         h->profile = 0;
         // ---- how far do the spikes reach?  probe the first and last column of W and of V
         int m = 0;
         double *dStat = nullptr;  // [absmax_in, absmax_out, probe absmax, extent(int)]
-        HIPCHK(dalloc(&dStat, 4));
+        HIPCHK(tmp.alloc(&dStat, 4));
         HIPCHK(hipMemsetAsync(dStat, 0, 4 * sizeof(double), st));
         int nmin = h->chains[0].nrows;
         for (int p = 1; p < P; ++p) nmin = std::min<int>(nmin, h->chains[p].nrows);
@@ -636,8 +661,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                     gbF[p] = g; gbF[p].maxsteps = nb; gbF[p].tile0 = g.tile0 + skip;
                     gbB[p] = g; gbB[p].maxsteps = nb;
                 }
-                for (int i = 0; i < 2; ++i) HIPCHK(dalloc(&dSubC[i], (size_t)P));
-                for (int i = 0; i < 4; ++i) HIPCHK(dalloc(&dSubG[i], (size_t)P));
+                for (int i = 0; i < 2; ++i) HIPCHK(tmp.alloc(&dSubC[i], (size_t)P));
+                for (int i = 0; i < 4; ++i) HIPCHK(tmp.alloc(&dSubG[i], (size_t)P));
                 HIPCHK(hipMemcpyAsync(dSubC[0], ct.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
                 HIPCHK(hipMemcpyAsync(dSubC[1], cb.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
                 HIPCHK(hipMemcpyAsync(dSubG[0], gtF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
@@ -673,10 +698,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         }
         h->spike_m = m;
         HIPCHK(hipStreamSynchronize(st));
-        for (int i = 0; i < 2; ++i) if (dSubC[i]) HIPCHK(hipFree(dSubC[i]));
-        for (int i = 0; i < 4; ++i) if (dSubG[i]) HIPCHK(hipFree(dSubG[i]));
-        HIPCHK(hipFree(sol));
-        HIPCHK(hipFree(dStat));
+        tmp.release(sol);
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 0, h->dCT, st));
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 1, h->dBT, st));
 
@@ -684,10 +706,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         std::vector<double *> Wsrc(nif), Vsrc(nif);
         double *dWif = nullptr, *dVif = nullptr, *dWork = nullptr;
         int *dFlag = nullptr;
-        HIPCHK(dalloc(&dWif, (size_t)nif * kk));
-        HIPCHK(dalloc(&dVif, (size_t)nif * kk));
-        HIPCHK(dalloc(&dWork, (size_t)nif * 2 * kk));
-        HIPCHK(dalloc(&dFlag, (size_t)nif));
+        HIPCHK(tmp.alloc(&dWif, (size_t)nif * kk));
+        HIPCHK(tmp.alloc(&dVif, (size_t)nif * kk));
+        HIPCHK(tmp.alloc(&dWork, (size_t)nif * 2 * kk));
+        HIPCHK(tmp.alloc(&dFlag, (size_t)nif));
         HIPCHK(hipMemsetAsync(dFlag, 0, sizeof(int) * nif, st));
         HIPCHK(dalloc(&h->dWT, (size_t)nif * kk));
         HIPCHK(dalloc(&h->dVT, (size_t)nif * kk));
@@ -721,7 +743,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         std::vector<int> flags(nif, 0);
         HIPCHK(hipMemcpyAsync(flags.data(), dFlag, sizeof(int) * nif, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(hipFree(dWif)); HIPCHK(hipFree(dVif)); HIPCHK(hipFree(dWork)); HIPCHK(hipFree(dFlag));
+        tmp.release(dWork);
         for (int i = 0; i < nif; ++i)
             if (flags[i]) return fail(h, SPIKE_ERR_SINGULAR, "interface system %d is singular", i);
 
@@ -819,18 +841,16 @@ extern "C" int spike_apply(spike_handle h, const double *x, double *y, int on_de
     if (!h || !x || !y || x == y) return fail(h, SPIKE_ERR_ARG, "spike_apply: bad pointers (x must differ from y)");
     if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_apply before setup");
     if (on_device) return apply_dev(h, x, y);
+    TmpPool tmp;
     double *dx = nullptr, *dy = nullptr;
-    HIPCHK(dalloc(&dx, (size_t)h->n));
-    HIPCHK(dalloc(&dy, (size_t)h->n));
+    HIPCHK(tmp.alloc(&dx, (size_t)h->n));
+    HIPCHK(tmp.alloc(&dy, (size_t)h->n));
     HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
-    int rc = apply_dev(h, dx, dy);
-    if (rc == SPIKE_OK) {
-        hipError_t e = hipMemcpyAsync(y, dy, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail(h, SPIKE_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(dx); (void)hipFree(dy);
-    return rc;
+    const int rc = apply_dev(h, dx, dy);
+    if (rc != SPIKE_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
+    HIPCHK(hipMemcpyAsync(y, dy, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SPIKE_OK;
 }
 
 extern "C" int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches)

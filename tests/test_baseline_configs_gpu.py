@@ -1,0 +1,94 @@
+"""One parity test per BASELINE.json config (the GPU ones), at the sizes BASELINE.json names.
+
+config 1 (tridiagonal N=16384, 4 partitions, CPU plumbing) lives in tests/test_oracle.py / test_spike_gpu.py CASES.
+config 4 (MC64 + Fiedler -> band -> PCSPIKE in GMRES) is tests/test_host_gpu.py::test_config4_pipeline_*.
+config 5 (8 GPUs, 8 partitions/GPU) runs here with 8 THREAD ranks on one GPU at N = 2^17 per rank through the
+loopback transport (same algorithm and buffers as the RCCL path)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_config2_banded_1M_k32_64_partitions(spike, oracle):
+    """Banded N=1M half-bw=32 fp64, 64 partitions: full size against the oracle (it finishes in seconds)."""
+    import torch
+    N, K, P = 2 ** 20, 32, 64
+    band = oracle.gen_band(N, K, seed=12345, delta=1.2)
+    f = oracle.gen_vec(N)
+    ref = oracle.Spike(band, P)
+    sp = spike.Spike(partitions=P, variant="coupled").setup_band(torch.from_numpy(band).cuda())
+    x = sp.apply(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert _rel(x, ref.apply(f, 1)) <= 1e-10
+    i = sp.info()
+    assert i.P_local == 64 and i.Kp == 32 and i.rows_per_block == 32
+    sp.set_option("variant", "decoupled")
+    xd = sp.apply(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert _rel(xd, ref.apply(f, 0)) <= 1e-10
+    # exact-solution round trip, the reference's acceptance check (src/testbed2.c:120-132)
+    sp.set_option("variant", "coupled")
+    u = np.ones(N)
+    b = oracle.band_matvec(band, u)
+    assert np.abs(sp.apply(b) - u).max() <= 1e-10
+
+
+def test_config3_banded_4M_k256(spike, oracle):
+    """Banded N=4M half-bw=256 (the MFMA block-LU path, in-place window): size-independent properties."""
+    import torch
+    N, K = 4 * 2 ** 20, 256
+    band = spike.gen_band_device(N, K, seed=12345, delta=1.2)
+    sp = spike.Spike(partitions=0, variant="coupled").setup_band(band)
+    u = torch.ones(N, dtype=torch.float64, device="cuda")
+    b = sp.matvec(u)
+    x = sp.apply(b)
+    torch.cuda.synchronize()
+    assert float((x - u).abs().max()) <= 1e-9
+    v = torch.from_numpy(oracle.gen_vec(N)).cuda()
+    bv = sp.matvec(v)
+    xv = sp.apply(bv)
+    assert float((sp.matvec(xv) - bv).norm() / bv.norm()) <= 1e-12       # residual of the preconditioned solve
+    assert float((sp.apply(b + 3.0 * bv) - (x + 3.0 * xv)).abs().max()) <= 1e-9   # linearity
+    i = sp.info()
+    assert i.Kp == 256 and i.waves_per_chain == 8 and i.nboost == 0
+    # a slice of the same system small enough for the oracle: first 2^17 rows as their own system
+    n = 2 ** 17
+    bs = oracle.gen_band(n, K, seed=12345, delta=1.2)
+    f = oracle.gen_vec(n)
+    sps = spike.Spike(partitions=16).setup_band(bs)
+    assert _rel(sps.apply(f), oracle.Spike(bs, 16).apply(f, 1)) <= 1e-10
+
+
+def test_config5_eight_ranks_eight_partitions_each(spike, oracle):
+    """Banded half-bw=128, 8 partitions per GPU, 8 ranks with the tips exchanged by all-gather."""
+    import torch
+    G, Pl, K = 8, 8, 128
+    n_rank = 2 ** 14
+    N = G * n_rank
+    band = oracle.gen_band(N, K, seed=12345, delta=1.2)
+    f = oracle.gen_vec(N)
+    out, err = [None] * G, [None] * G
+
+    def work(r):
+        try:
+            sp = spike.Spike(partitions=Pl)
+            sp.comm_init_local(G, r, 555)
+            r0 = r * n_rank
+            sp.setup_band(np.ascontiguousarray(band[:, r0:r0 + n_rank]), n_global=N, row0=r0)
+            out[r] = sp.apply(torch.from_numpy(f[r0:r0 + n_rank].copy()).cuda()).cpu().numpy()
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    x = np.concatenate(out)
+    assert _rel(x, oracle.Spike(band, G * Pl).apply(f, 1)) <= 1e-10

@@ -75,6 +75,7 @@ typedef struct {
     int32_t passes;          /* passes over the packed factors per apply: 1, or 2 (coupled variant re-solving) */
     int32_t spike_rows;      /* rows kept of every spike (0: none, the coupled variant re-solves) */
     int64_t spike_bytes;     /* bytes of stored spikes read per coupled apply */
+    int32_t chains_local;    /* chains the kernels sweep: P_local, or a multiple of it when "subsplit" cut the partitions */
 } spike_info;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -87,6 +88,9 @@ const char *spike_last_error(spike_handle h);
  *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1),
  *       "spike_storage" ("auto"|"off": keep the spikes' decayed part and apply the coupled variant in ONE pass
  *        when they are short, else/off: second pass over the factors), "spike_tol" (relative drop level, 1e-17),
+ *       "subsplit" ("auto"|"off": a caller-chosen partition count is honoured, but each partition may be swept as
+ *        several chains when setup MEASURES that the spikes die inside a chain, which leaves the preconditioner
+ *        unchanged to rounding; off: exactly one chain per partition),
  *       "profile" (0|1: record HIP events around the sweep launches)                                  */
 int spike_set_option(spike_handle h, const char *key, const char *value);
 /* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */

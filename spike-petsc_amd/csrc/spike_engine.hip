@@ -89,6 +89,7 @@ struct spike_handle_s {
     double boost_rel = 1e-10;
     int keep_band = 1;
     int profile = 0;
+    int subsplit = 1;           // 1 = cut a caller-chosen partition into sub-chains when the spikes provably die inside them
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
     double spike_tol = 1e-17;   // relative magnitude below which spike rows are dropped
     hipStream_t stream = nullptr;
@@ -100,7 +101,8 @@ struct spike_handle_s {
     // problem
     bool ready = false;
     int64_t n_global = 0, row0 = 0, n = 0;
-    int K = 0, P = 0;
+    int K = 0, P = 0;           // P = chains the kernels sweep
+    int P_user = 0, S = 1;      // the caller's partitions and how many chains each one is cut into (P = P_user * S)
     SweepCfg cfg{64, 32, 1};
     std::vector<ChainDesc> chains;
     std::vector<GroupDesc> groups;
@@ -122,6 +124,8 @@ struct spike_handle_s {
     double *dWf = nullptr, *dVf = nullptr;                // stored spikes, per chain column-major K x m
     double *dXb = nullptr, *dXt = nullptr;                // tip solutions, (P+2) x K (slot p+1 = chain p)
     IfaceDesc *dIfsFast = nullptr;
+    IfaceDesc *dIfsInt = nullptr, *dIfsFastInt = nullptr;  // only the cuts INSIDE caller partitions (decoupled variant, S > 1)
+    int nif_int = 0;
     int spike_m = 0;                                      // rows kept per spike (0 = re-solve variant)
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dHalo = nullptr;                              // matvec halo: [K left | K right]
@@ -259,7 +263,7 @@ static void free_factors(spike_handle h)
     h->ownA = false;
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
-    F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); h->spike_m = 0;
+    F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dHalo); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
@@ -311,6 +315,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "boost") h->boost_rel = atof(val);
     else if (k == "keep_band") h->keep_band = atoi(val);
     else if (k == "profile") h->profile = atoi(val);
+    else if (k == "subsplit") h->subsplit = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
     else return fail(h, SPIKE_ERR_ARG, "unknown option '%s'", key);
@@ -380,20 +385,27 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
 static int build_chains(spike_handle h)
 {
     const int64_t n = h->n;
-    const int P = h->P;
+    const int PU = h->P_user, S = h->S;
+    const int P = PU * S;
+    h->P = P;
     const int R = h->cfg.R, CPW = h->cfg.CPW();
     const int64_t nblk = (n + BLK - 1) / BLK;
-    if (nblk < P) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", P, P, (long long)nblk);
+    if (nblk < PU) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", PU, PU, (long long)nblk);
     h->chains.resize(P);
-    for (int p = 0; p < P; ++p) {
-        int64_t r0 = (nblk * (int64_t)p) / P * BLK, r1 = (nblk * (int64_t)(p + 1)) / P * BLK;
-        if (r1 > n || p == P - 1) r1 = n;
-        if (r0 > n) r0 = n;
-        const int64_t rows = r1 - r0;
-        if (rows < (h->K > 1 ? h->K : 1)) return fail(h, SPIKE_ERR_PARTITION, "partition %d has %lld rows < K=%d", p, (long long)rows, h->K);
-        h->chains[p].row0 = r0;
-        h->chains[p].nrows = (int32_t)rows;
-        h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
+    for (int pu = 0; pu < PU; ++pu) {
+        // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range evenly
+        const int64_t b0 = (nblk * (int64_t)pu) / PU, b1 = (nblk * (int64_t)(pu + 1)) / PU;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const int p = pu * S + sidx;
+            int64_t r0 = (b0 + ((b1 - b0) * sidx) / S) * BLK, r1 = (b0 + ((b1 - b0) * (sidx + 1)) / S) * BLK;
+            if (r1 > n || p == P - 1) r1 = n;
+            if (r0 > n) r0 = n;
+            const int64_t rows = r1 - r0;
+            if (rows < (h->K > 1 ? h->K : 1)) return fail(h, SPIKE_ERR_PARTITION, "partition %d has %lld rows < K=%d", pu, (long long)rows, h->K);
+            h->chains[p].row0 = r0;
+            h->chains[p].nrows = (int32_t)rows;
+            h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
+        }
     }
     const int ng = (P + CPW - 1) / CPW;
     h->groups.resize(ng);
@@ -500,7 +512,7 @@ __global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv
 
 // ---- setup -----------------------------------------------------------------------------------------------
 static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
-                      int on_device)
+                      int on_device, bool allow_subsplit = true)
 {
     if (!h) return SPIKE_ERR_ARG;
     if (n <= 0 || n_global < n || row0 < 0 || row0 + n > n_global || K < 0 || !band || ld < n)
@@ -515,7 +527,18 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     const auto t_start = std::chrono::steady_clock::now();
     h->cfg = cfg;
     h->n_global = n_global; h->row0 = row0; h->n = n; h->K = K;
-    h->P = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n);
+    h->P_user = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n);
+    h->S = 1;
+    if (h->opt_partitions > 0 && h->subsplit && allow_subsplit && K > 0) {
+        // A caller-chosen P may leave most CUs without a chain.  Cut every partition into S chains; the cuts are
+        // treated like partition interfaces (truncated coupling), which reproduces the P-partition preconditioner to
+        // rounding iff the spikes die inside a chain -- measured below, and undone (S = 1) when they do not.
+        const int want = auto_partitions(cfg, K, n);
+        int S = want / h->P_user;
+        const int64_t nblk = (n + BLK - 1) / BLK;
+        while (S > 1 && nblk / ((int64_t)h->P_user * S) < 1) --S;
+        if (S > 1) h->S = S;
+    }
     int rc = build_chains(h);
     if (rc) return rc;
     const int P = h->P;
@@ -605,7 +628,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(hipMemsetAsync(dStat, 0, 4 * sizeof(double), st));
         int nmin = h->chains[0].nrows;
         for (int p = 1; p < P; ++p) nmin = std::min<int>(nmin, h->chains[p].nrows);
-        if (h->spike_storage) {
+        int extent = 0;
+        if (h->spike_storage || h->S > 1) {
             for (int which = 0; which < 2; ++which) {
                 HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
                 for (int t = 0; t < 2; ++t) {
@@ -620,15 +644,30 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                     HIPCHK(launch_spike_extent(sol, h->dChains, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
                 }
             }
-            int extent = 0;
             HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+        }
+        if (h->S > 1) {
+            // do the spikes die (below spike_tol of their peak) before they reach the far end of the shortest chain?
+            double bad = ((int64_t)(extent * 1.06) + K > nmin) ? 1.0 : 0.0;
+            if (h->nranks > 1) {  // every rank must take the same decision (the redo below is collective)
+                HIPCHK(hipMemcpyAsync(dStat + 2, &bad, sizeof(double), hipMemcpyHostToDevice, st));
+                if ((rc = coll_allreduce(h, dStat + 2, 1, NCCL_MAX))) return rc;
+                HIPCHK(hipMemcpyAsync(&bad, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+            if (bad != 0.0) {
+                h->profile = keep_prof;
+                return setup_impl(h, n_global, row0, n, K, band, ld, on_device, false);
+            }
+        }
+        if (h->spike_storage) {
             m = (int)(((int64_t)(extent * 1.06) + 64 + 63) / 64 * 64);  // 2 probed columns -> small margin; verified below
             if (m > nmin) m = nmin;
             // worth it only while the correction stays well below a pass over the factors
             const double corr_bytes = 2.0 * m * (double)K * 8.0 * P;
             const double pass_bytes = 2.0 * (double)h->ntiles * (double)cfg.tile_doubles() * 8.0;
-            if (corr_bytes > 0.6 * pass_bytes) m = 0;
+            if (corr_bytes > 0.85 * pass_bytes) m = 0;  // 1 + corr/pass passes against 2 for re-solving
         }
         if (m > 0) {
             HIPCHK(dalloc(&h->dWf, (size_t)P * K * m));
@@ -776,6 +815,19 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         for (auto &d : ifs) { d.xb_out = nullptr; d.xt_out = nullptr; }
         HIPCHK(dalloc(&h->dIfs, (size_t)nif));
         HIPCHK(hipMemcpyAsync(h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+        // cuts inside a caller partition stay coupled even in the decoupled (block-Jacobi) variant
+        std::vector<int> internal;
+        if (h->S > 1)
+            for (int i = 0; i < nif_local; ++i)
+                if ((i + 1) % h->S != 0) internal.push_back(i);
+        h->nif_int = (int)internal.size();
+        if (h->nif_int > 0) {
+            std::vector<IfaceDesc> ii;
+            for (int i : internal) ii.push_back(ifs[i]);
+            HIPCHK(dalloc(&h->dIfsInt, ii.size()));
+            HIPCHK(hipMemcpyAsync(h->dIfsInt, ii.data(), sizeof(IfaceDesc) * ii.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
         if (h->spike_m > 0) {
             // one-pass variant: the interface kernel only has to deliver the tip solutions
             HIPCHK(dalloc(&h->dXb, (size_t)(P + 2) * K));
@@ -792,6 +844,13 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (ib_next >= 0) { ff[ib_next].xb_out = h->dXb + (size_t)P * K; ff[ib_next].xt_out = h->dXt + (size_t)(P + 1) * K; }
             HIPCHK(dalloc(&h->dIfsFast, (size_t)nif));
             HIPCHK(hipMemcpyAsync(h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+            if (h->nif_int > 0) {
+                std::vector<IfaceDesc> fi;
+                for (int i : internal) fi.push_back(ff[i]);
+                HIPCHK(dalloc(&h->dIfsFastInt, fi.size()));
+                HIPCHK(hipMemcpyAsync(h->dIfsFastInt, fi.data(), sizeof(IfaceDesc) * fi.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
         }
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -818,17 +877,28 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     h->nev = 0;
     int rc = run_pass(h, x, y, false);
     if (rc) return rc;
-    if (h->variant == SPIKE_VARIANT_COUPLED && h->nif > 0) {
-        const bool multi = h->nranks > 1;
-        hipLaunchKernelGGL(k_gather_tips, dim3(h->P), dim3(64), 0, st, y, h->K, h->dChains, h->P, h->dTips, multi ? h->dSend : nullptr);
+    const bool coupled = h->variant == SPIKE_VARIANT_COUPLED;
+    const int nif = coupled ? h->nif : h->nif_int;  // decoupled: only the cuts inside the caller's partitions
+    if (nif > 0) {
+        const bool multi = coupled && h->nranks > 1;
+        const int K = h->K, P = h->P;
+        hipLaunchKernelGGL(k_gather_tips, dim3(P), dim3(64), 0, st, y, K, h->dChains, P, h->dTips, multi ? h->dSend : nullptr);
         HIPCHK(hipGetLastError());
-        if (multi && (rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K))) return rc;
+        if (multi && (rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K))) return rc;
         if (h->spike_m > 0) {
             // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
-            HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfsFast, st));
-            HIPCHK(launch_spike_correct(h->K, h->spike_m, h->dChains, h->P, h->dWf, h->dVf, h->dXb, h->dXt, y, st));
+            if (!coupled) {  // tip solutions of the caller-level interfaces must read as zero
+                HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
+                HIPCHK(hipMemsetAsync(h->dXt, 0, sizeof(double) * (P + 2) * K, st));
+            }
+            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfsFast : h->dIfsFastInt, st));
+            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st));
         } else {
-            HIPCHK(launch_iface_apply(h->K, h->nif, h->dIfs, st));
+            if (!coupled) {
+                HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
+                HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
+            }
+            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfs : h->dIfsInt, st));
             rc = run_pass(h, x, y, true);
             if (rc) return rc;
         }
@@ -1110,12 +1180,13 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     if (!h || !o) return SPIKE_ERR_ARG;
     memset(o, 0, sizeof *o);
     o->n_local = h->n; o->n_global = h->n_global; o->row0 = h->row0; o->K = h->K; o->Kp = h->cfg.KP();
-    o->P_local = h->P; o->P_global = h->P * h->nranks; o->variant = h->variant;
+    o->P_local = h->P_user; o->P_global = h->P_user * h->nranks; o->variant = h->variant;
+    o->chains_local = h->P;
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
     o->nboost = h->nboost;
     o->factor_bytes = (int64_t)(2 * (size_t)h->ntiles * (size_t)h->cfg.tile_doubles() + (size_t)h->n) * 8;
     o->iface_bytes = (int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) * (int64_t)h->K * h->K * 8;
-    o->passes = (h->variant == SPIKE_VARIANT_COUPLED && h->nif > 0 && h->spike_m == 0) ? 2 : 1;
+    o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;
     o->spike_bytes = (int64_t)2 * h->spike_m * (int64_t)h->K * 8 * h->P;
     o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
@@ -1127,10 +1198,10 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
     if (!h || !buf || !len) return SPIKE_ERR_ARG;
     snprintf(buf, len,
              "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
-             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d\n",
-             (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P,
+             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d, chains = %d\n",
+             (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P_user,
              h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
-             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m);
+             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->P);
     return SPIKE_OK;
 }
 
@@ -1139,10 +1210,13 @@ extern "C" int spike_get_tips(spike_handle h, double *Vb, double *Wt)
     if (!h || !Vb || !Wt) return SPIKE_ERR_ARG;
     if (!h->ready) return fail(h, SPIKE_ERR_STATE, "no factors");
     const size_t kk = (size_t)h->K * h->K;
-    if (h->P < 2 || kk == 0 || !h->dVb) return SPIKE_OK;
-    // interface i: V of chain i, W of chain i+1
-    HIPCHK(hipMemcpy(Vb, h->dVb, sizeof(double) * (h->P - 1) * kk, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(Wt, h->dWt + kk, sizeof(double) * (h->P - 1) * kk, hipMemcpyDeviceToHost));
+    if (h->P_user < 2 || kk == 0 || !h->dVb) return SPIKE_OK;
+    // interface i of the caller's partitioning: V of the last chain of partition i, W of the first chain of i+1
+    for (int i = 0; i < h->P_user - 1; ++i) {
+        const size_t cv = (size_t)(i + 1) * h->S - 1, cw = (size_t)(i + 1) * h->S;
+        HIPCHK(hipMemcpy(Vb + (size_t)i * kk, h->dVb + cv * kk, sizeof(double) * kk, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(Wt + (size_t)i * kk, h->dWt + cw * kk, sizeof(double) * kk, hipMemcpyDeviceToHost));
+    }
     return SPIKE_OK;
 }
 

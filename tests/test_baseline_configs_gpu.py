@@ -28,6 +28,12 @@ def test_config2_banded_1M_k32_64_partitions(spike, oracle):
     assert _rel(x, ref.apply(f, 1)) <= 1e-10
     i = sp.info()
     assert i.P_local == 64 and i.Kp == 32 and i.rows_per_block == 32
+    assert i.chains_local > 64 and i.chains_local % 64 == 0      # 64 partitions swept as many chains (verified cut)
+    sp_off = spike.Spike(partitions=P, variant="coupled")
+    sp_off.set_option("subsplit", "off")
+    sp_off.setup_band(torch.from_numpy(band).cuda())
+    assert sp_off.info().chains_local == 64
+    assert _rel(sp_off.apply(torch.from_numpy(f).cuda()).cpu().numpy(), ref.apply(f, 1)) <= 1e-10
     sp.set_option("variant", "decoupled")
     xd = sp.apply(torch.from_numpy(f).cuda()).cpu().numpy()
     assert _rel(xd, ref.apply(f, 0)) <= 1e-10

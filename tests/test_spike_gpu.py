@@ -70,16 +70,35 @@ def test_coupled_one_pass_and_two_pass_agree(spike, oracle, torch_cuda, N, K, P)
     band = oracle.gen_band(N, K, delta=0.8)
     f = oracle.gen_vec(N)
     xo = oracle.Spike(band, P).apply(f, 1)
-    sp1 = spike.Spike(partitions=P).setup_band(band)
+    sp1 = spike.Spike(partitions=P)
+    sp1.set_option("subsplit", "off")      # one chain per partition: long chains, short spikes -> one pass
+    sp1.setup_band(band)
     i1 = sp1.info()
     assert i1.passes == 1 and 0 < i1.spike_rows <= N // P
     assert _rel(sp1.apply(f), xo) <= TOL
     sp2 = spike.Spike(partitions=P)
+    sp2.set_option("subsplit", "off")
     sp2.set_option("spike_storage", "off")
     sp2.setup_band(band)
     i2 = sp2.info()
     assert i2.passes == 2 and i2.spike_rows == 0
     assert _rel(sp2.apply(f), xo) <= TOL
+
+
+def test_subsplit_is_undone_when_spikes_do_not_die(spike, oracle, torch_cuda):
+    """-1,2,-1: the library first cuts the 2 caller partitions into chains, measures that the spikes reach across a
+    chain, and falls back to one chain per partition -- the result must be the 2-partition preconditioner."""
+    N, P = 2 ** 15, 2
+    band = np.zeros((3, N)); band[0, 1:] = -1.0; band[1, :] = 2.0; band[2, :-1] = -1.0
+    f = oracle.gen_vec(N)
+    sp = spike.Spike(partitions=P).setup_band(band)
+    assert sp.info().chains_local == P and sp.info().P_local == P
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-9
+    # dominant system, same sizes: the cut is kept and changes nothing beyond rounding
+    band = oracle.gen_band(N, 1, delta=1.2)
+    sp = spike.Spike(partitions=P).setup_band(band)
+    assert sp.info().chains_local > P
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-10
 
 
 def test_spikes_that_do_not_decay(spike, oracle, torch_cuda):
@@ -104,7 +123,12 @@ def test_spikes_that_do_not_decay(spike, oracle, torch_cuda):
         if off > 0: band[d, N - off:] = 0.0
     sp = spike.Spike(partitions=P).setup_band(band)
     assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-8
+    i = sp.info()   # full spikes cost 40/64 of a pass here: kept (1 pass) or not (2 passes) -- both are the same algebra
+    assert (i.passes, i.spike_rows) in ((1, N // P), (2, 0))
+    sp.set_option("spike_storage", "off")
+    sp.setup_band(band)
     assert sp.info().passes == 2 and sp.info().spike_rows == 0
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-8
 
 
 @pytest.mark.parametrize("N,K,P", [(8192, 8, 8), (16384, 64, 8), (32768, 128, 16)])

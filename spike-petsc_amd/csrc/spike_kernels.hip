@@ -927,7 +927,10 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
     return hipGetLastError();
 }
 
-// y[a] = sum_c MT[c*K + a] * x[c];  256 threads = nparts groups of KA lanes, partial sums via LDS
+// y[a] = sum_c MT[c*K + a] * x[c];  IFT threads = nparts groups of KA lanes, partial sums via LDS.
+// 1024 threads per interface: the three dependent mat-vecs are latency-bound, so the only lever is loads in flight
+// (K/nparts = 16 sequential loads per thread at K = 128 instead of 64 with 256 threads).
+constexpr int IFT = 1024;
 __device__ __forceinline__ double iface_matvec(const double *MT, const double *xs, int K, int KA, int nparts, int a,
                                                int part, double *redb)
 {
@@ -942,18 +945,18 @@ __device__ __forceinline__ double iface_matvec(const double *MT, const double *x
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_iface_apply(int K, const IfaceDesc *ifs)
+__global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs)
 {
     extern __shared__ double sh[];
     double *gb = sh, *gt = sh + K, *v1 = sh + 2 * K, *v2 = sh + 3 * K;
-    __shared__ double redb[256];
+    __shared__ double redb[IFT];
     const IfaceDesc d = ifs[blockIdx.x];
     const int tid = threadIdx.x;
     int KA = 1;
     while (KA < K) KA <<= 1;
-    const int nparts = 256 / KA;
+    const int nparts = IFT / KA;
     const int a = tid % KA, part = tid / KA;
-    for (int t = tid; t < K; t += 256) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
+    for (int t = tid; t < K; t += IFT) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
     __syncthreads();
     // t = gt - W gb
     double s = iface_matvec(d.WT, gb, K, KA, nparts, a, part, redb);
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256) void k_iface_apply(int K, const IfaceDesc *ifs
 hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st)
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(256), (size_t)4 * K * sizeof(double), st, K, ifs);
+    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(IFT), (size_t)4 * K * sizeof(double), st, K, ifs);
     return hipGetLastError();
 }
 
@@ -1065,27 +1068,40 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
     const double *src = which == 0 ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
     for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = src[c];
     __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m) return;
+    const int r = 2 * (blockIdx.x * blockDim.x + threadIdx.x);  // this lane's row pair (m is even: a multiple of 64,
+    if (r >= m) return;                                         //  or the chain length, itself a multiple of 64 or odd-tailed)
     const double *S = (which == 0 ? Wf : Vf) + (int64_t)p * K * m + r;
+    const bool pair = (r + 1 < m) && ((m & 1) == 0);
     double a0 = 0.0, a1 = 0.0;
-    int c = 0;
-    for (; c + 1 < K; c += 2) {
-        a0 = fma(S[(int64_t)c * m], tip[c], a0);
-        a1 = fma(S[(int64_t)(c + 1) * m], tip[c + 1], a1);
+    if (pair) {
+#pragma unroll 4
+        for (int c = 0; c < K; ++c) {
+            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(S + (int64_t)c * m));
+            a0 = fma(v.x, tip[c], a0);
+            a1 = fma(v.y, tip[c], a1);
+        }
+    } else {
+        for (int c = 0; c < K; ++c) {
+            a0 = fma(S[(int64_t)c * m], tip[c], a0);
+            if (r + 1 < m) a1 = fma(S[(int64_t)c * m + 1], tip[c], a1);
+        }
     }
-    if (c < K) a0 = fma(S[(int64_t)c * m], tip[c], a0);
     const int64_t row = cd.row0 + (which == 0 ? r : cd.nrows - m + r);
     // when 2m > nrows the two windows overlap: the two contributions to a row must not race
-    if (2 * m > cd.nrows) atomicAdd(x + row, -(a0 + a1));
-    else x[row] -= a0 + a1;
+    if (2 * m > cd.nrows) {
+        atomicAdd(x + row, -a0);
+        if (r + 1 < m) atomicAdd(x + row + 1, -a1);
+    } else {
+        x[row] -= a0;
+        if (r + 1 < m) x[row + 1] -= a1;
+    }
 }
 
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spike_correct, dim3((m + 255) / 256, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
+    hipLaunchKernelGGL(k_spike_correct, dim3((m + 511) / 512, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
                        chains, Wf, Vf, xb, xt, x);
     return hipGetLastError();
 }

@@ -1,4 +1,4 @@
-// spike_csr.hip -- CSR entry of the engine: band extraction + setup.
+// spike_csr.hip -- host steps of the CSR entry of the engine (spike_setup_csr itself is in spike_engine.hip).
 //
 // Follows MatCreateSubMatrixBanded, /root/reference/src/matbanded.c:22-107, line for line in
 // MEANING (not in code): like the reference this step runs on the host in one pass order, so
@@ -48,23 +48,3 @@ extern "C" int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja
     return SPIKE_OK;
 }
 
-extern "C" int spike_set_extracted(spike_handle h, int k, double frac);
-
-extern "C" int spike_csr_extract_setup(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
-                                       int kmax, double frac, int *k_out, double *frac_out)
-{
-    if (!h) return SPIKE_ERR_ARG;
-    int k = 0;
-    double f = 0.0;
-    int rc = spike_csr_band_k(n, ia, ja, a, kmax, frac, &k, &f);
-    if (rc) return rc;
-    std::vector<double> band((size_t)(2 * k + 1) * (size_t)n);
-    rc = spike_csr_to_band(n, ia, ja, a, k, band.data(), n);
-    if (rc) return rc;
-    rc = spike_setup_band(h, n, 0, n, k, band.data(), n, 0);
-    if (rc) return rc;
-    spike_set_extracted(h, k, f);
-    if (k_out) *k_out = k;
-    if (frac_out) *frac_out = f;
-    return SPIKE_OK;
-}

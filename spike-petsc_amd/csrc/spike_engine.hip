@@ -24,6 +24,9 @@
 
 using namespace spike;
 
+extern "C" int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int kmax, double frac,
+                                int *k_out, double *frac_out);
+
 // ---- RCCL through dlopen: the library has no link-time dependency on librccl ----------------
 typedef struct ncclComm *ncclComm_t_;
 typedef struct { char internal[128]; } ncclUniqueId_;
@@ -1165,13 +1168,45 @@ extern "C" int spike_dev_upload(void *dst, const void *src, size_t bytes) { retu
 extern "C" int spike_dev_download(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP; }
 
 // ---- CSR entry: band extraction (reference src/matbanded.c:22-107) then setup ----------------------------
-extern "C" int spike_csr_extract_setup(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja,
-                                       const double *a, int kmax, double frac, int *k_out, double *frac_out);
-
+// The half-bandwidth rule runs on the host in the reference's own pass order (spike_csr_band_k: bit-identical k and
+// fraction); the matrix itself goes to the device as CSR (nnz entries over PCIe, not (2k+1) n) and is scattered into the
+// diagonal-major band there.
 extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
                                int kmax, double frac, int *k_out, double *frac_out)
 {
-    return spike_csr_extract_setup(h, n, ia, ja, a, kmax, frac, k_out, frac_out);
+    if (!h || n <= 0 || !ia || !ja || !a) return SPIKE_ERR_ARG;
+    if (h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "spike_setup_csr is single-rank; use spike_setup_band per rank");
+    if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "matrix too large");
+    int k = 0;
+    double f = 0.0;
+    int rc = spike_csr_band_k(n, ia, ja, a, kmax, frac, &k, &f);
+    if (rc) return fail(h, rc, "band rule failed (column index out of range?)");
+    const int64_t nnz = ia[n];
+    std::vector<int32_t> j32((size_t)nnz);
+    for (int64_t q = 0; q < nnz; ++q) j32[(size_t)q] = (int32_t)ja[q];
+    TmpPool tmp;
+    int64_t *dia = nullptr;
+    int32_t *dja = nullptr;
+    double *da = nullptr, *dband = nullptr;
+    HIPCHK(tmp.alloc(&dia, (size_t)n + 1));
+    HIPCHK(tmp.alloc(&dja, (size_t)nnz));
+    HIPCHK(tmp.alloc(&da, (size_t)nnz));
+    HIPCHK(tmp.alloc(&dband, (size_t)(2 * k + 1) * (size_t)n));
+    HIPCHK(hipMemcpyAsync(dia, ia, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dja, j32.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(launch_csr_to_band(n, dia, dja, da, k, dband, n, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int keep = h->keep_band;
+    h->keep_band = 1;  // dband is scratch: the library must hold its own copy
+    rc = setup_impl(h, n, 0, n, k, dband, n, 1);
+    h->keep_band = keep;
+    if (rc) return rc;
+    h->k_extracted = k;
+    h->frac_extracted = f;
+    if (k_out) *k_out = k;
+    if (frac_out) *frac_out = f;
+    return SPIKE_OK;
 }
 
 // ---- introspection ---------------------------------------------------------------------------------------------
@@ -1220,10 +1255,3 @@ extern "C" int spike_get_tips(spike_handle h, double *Vb, double *Wt)
     return SPIKE_OK;
 }
 
-extern "C" int spike_set_extracted(spike_handle h, int k, double frac)
-{
-    if (!h) return SPIKE_ERR_ARG;
-    h->k_extracted = k;
-    h->frac_extracted = frac;
-    return SPIKE_OK;
-}

@@ -102,6 +102,8 @@ hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hip
 // Krylov pieces (spike_krylov.hip)
 hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int tpr, const double *x,
                              double *y, hipStream_t st);
+hipError_t launch_csr_to_band(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int K, double *band,
+                              int64_t ld, hipStream_t st);
 hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out /*nvec*/,
                        hipStream_t st);
 hipError_t launch_axpys(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,

@@ -11,6 +11,7 @@
  *                                          typo in the composed-function name, :311,341; these ones work)
  *   KSPCreate_Reorder + ops               src/kspreorder.c:1-223      option -mat_ordering_type (:146), prefix reorder_ (:221)
  *   MatGetOrdering_WBM                    src/petsc_mat_wbm.c:13-61   (HSLmc64AD job 5 -> spike_mc64_job5)
+ *   MatGetOrdering_AWBM                   src/petsc_mat_awbm.c:42-225 (approximate matching, 5 greedy phases -> spike_awbm)
  *   MatGetOrdering_Fiedler                src/petsc_mat_fiedler.c:11-58 (HSL_MC73 absent -> spike_fiedler_order, own spec)
  *   SpikePetscRegisterAll                 LoadModules, src/testbed2.c:61-73
  *
@@ -80,6 +81,11 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y);
 PetscErrorCode MatPermute(Mat A, IS rowp, IS colp, Mat *B); /* B[i][j] = A[rowp[i]][colp[j]] */
 PetscErrorCode MatComputeBandwidth(Mat A, PetscReal fraction, PetscInt *bw);
 PetscErrorCode MatCreateSubMatrixBanded(Mat A, PetscInt *kmax, PetscReal *frac, Mat *B);
+/* file formats of the reference's drivers: PETSc binary AIJ (testbed2.c:93-96) and MatrixMarket (wbm.c:476-477,520-522) */
+PetscErrorCode MatLoad(const char *petsc_binary_path, Mat *A);
+PetscErrorCode MatViewBinary(Mat A, const char *path);
+PetscErrorCode MatLoadMatrixMarket(const char *path, Mat *A);
+PetscErrorCode MatViewMatrixMarket(Mat A, const char *path);
 
 /* Vec (sequential, host array) */
 PetscErrorCode VecCreateSeq(PetscInt n, Vec *v);
@@ -103,6 +109,7 @@ typedef PetscErrorCode (*MatOrderingFn)(Mat, MatOrderingType, IS *, IS *);
 PetscErrorCode MatOrderingRegister(const char *name, MatOrderingFn fn);
 PetscErrorCode MatGetOrdering(Mat A, MatOrderingType type, IS *row, IS *col);
 PetscErrorCode MatGetOrdering_WBM(Mat A, MatOrderingType type, IS *row, IS *col);
+PetscErrorCode MatGetOrdering_AWBM(Mat A, MatOrderingType type, IS *row, IS *col);
 PetscErrorCode MatGetOrdering_Fiedler(Mat A, MatOrderingType type, IS *row, IS *col);
 PetscErrorCode MatGetOrdering_Natural(Mat A, MatOrderingType type, IS *row, IS *col);
 
@@ -155,6 +162,7 @@ PetscErrorCode KSPReorderGetOrdering(KSP ksp, IS *row, IS *col); /* borrowed ref
 /* the two vendored-kernel replacements, usable on their own */
 int spike_mc64_job5(int64_t n, const int64_t *colptr, const int64_t *rowind, const double *val, int64_t *perm,
                     double *u, double *v, int64_t *num);
+int spike_awbm(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, double *sr, double *sc);
 int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec);
 int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
                             int64_t *bandwidth);

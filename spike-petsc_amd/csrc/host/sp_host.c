@@ -324,6 +324,19 @@ PetscErrorCode MatGetOrdering_WBM(Mat A, MatOrderingType type, IS *row, IS *col)
     free(perm);
     return e;
 }
+/* src/petsc_mat_awbm.c:42-225: row IS = p (p[match[c]] = c), column IS = identity (:200-205) */
+PetscErrorCode MatGetOrdering_AWBM(Mat A, MatOrderingType type, IS *row, IS *col)
+{
+    (void)type;
+    const PetscInt n = A->n;
+    PetscInt *p = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
+    const int rc = spike_awbm(n, A->ia, A->ja, A->a, p, NULL, NULL);
+    if (rc) { free(p); return seterr(PETSC_ERR_LIB, rc == -2 ? "Column unmatched" : "AWBM failed"); }
+    PetscErrorCode e = ISCreateGeneral(n, p, row);
+    free(p);
+    if (e) return e;
+    return ISCreateStride(n, 0, 1, col);
+}
 /* src/petsc_mat_fiedler.c:11-58: one symmetric permutation, returned for rows and columns (:54-56) */
 PetscErrorCode MatGetOrdering_Fiedler(Mat A, MatOrderingType type, IS *row, IS *col)
 {
@@ -842,6 +855,7 @@ PetscErrorCode SpikePetscRegisterAll(void)
 {
     CHK(MatOrderingRegister("natural", MatGetOrdering_Natural));
     CHK(MatOrderingRegister("wbm", MatGetOrdering_WBM));         /* testbed2.c:66 */
+    CHK(MatOrderingRegister("awbm", MatGetOrdering_AWBM));       /* :67 */
     CHK(MatOrderingRegister("fiedler", MatGetOrdering_Fiedler)); /* :68 */
     CHK(PCRegister(PCNONE, PCCreate_None));
     CHK(PCRegister(PCSPIKE, PCCreate_Spike));

@@ -19,7 +19,7 @@ HOST_SYMBOLS = [
     "MatCreateSeqAIJWithArrays", "MatDestroy", "MatGetSize", "MatSeqAIJGetCSR", "MatMult", "MatPermute",
     "MatComputeBandwidth", "MatCreateSubMatrixBanded", "VecCreateSeq", "VecDestroy", "VecGetArray", "VecGetSize",
     "VecSet", "VecCopy", "VecAXPY", "VecNorm2", "VecPermute", "ISCreateGeneral", "ISCreateStride", "ISDestroy",
-    "ISGetIndices", "MatOrderingRegister", "MatGetOrdering", "MatGetOrdering_WBM", "MatGetOrdering_Fiedler",
+    "ISGetIndices", "MatOrderingRegister", "MatGetOrdering", "MatGetOrdering_WBM", "MatGetOrdering_AWBM", "MatGetOrdering_Fiedler",
     "MatGetOrdering_Natural", "PCRegister", "PCCreate", "PCSetType", "PCSetOptionsPrefix", "PCAppendOptionsPrefix",
     "PCSetOperators", "PCSetFromOptions", "PCSetUp", "PCApply", "PCReset", "PCDestroy", "PCView", "PCGetDiagonalScale",
     "PCCreate_Banded", "PCCreate_Spike", "PCCreate_None", "PCBandedSetMaxHalfBandwidth", "PCBandedSetNormFraction",
@@ -27,7 +27,7 @@ HOST_SYMBOLS = [
     "KSPAppendOptionsPrefix", "KSPSetOperators", "KSPGetPC", "KSPSetTolerances", "KSPSetFromOptions", "KSPSetUp",
     "KSPSolve", "KSPGetConvergedReason", "KSPGetIterationNumber", "KSPGetResidualNorm", "KSPView", "KSPDestroy",
     "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order",
-    "spike_profile_bandwidth",
+    "spike_profile_bandwidth", "spike_awbm", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
 ]
 
 _L = None
@@ -95,6 +95,11 @@ def lib():
     L.KSPDestroy.argtypes = [C.POINTER(vp)]
     L.KSPReorderGetOrdering.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.spike_mc64_job5.argtypes = [i64, i64p, i64p, dp, i64p, dp, dp, i64p]
+    L.spike_awbm.argtypes = [i64, i64p, i64p, dp, i64p, dp, dp]
+    L.MatLoad.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.MatLoadMatrixMarket.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.MatViewMatrixMarket.argtypes = [vp, C.c_char_p]
+    L.MatViewBinary.argtypes = [vp, C.c_char_p]
     L.spike_fiedler_order.argtypes = [i64, i64p, i64p, dp, i64p, dp]
     L.spike_profile_bandwidth.argtypes = [i64, i64p, i64p, i64p, i64p, i64p]
     _L = L
@@ -194,6 +199,16 @@ def mc64_job5(n, colptr, rowind, val):
     if rc:
         raise HostError("spike_mc64_job5 failed")
     return perm, u, v, num.value
+
+
+def awbm(n, ia, ja, a):
+    ia, ja, a = _i(ia), _i(ja), _d(a)
+    perm = np.zeros(n, dtype=np.int64)
+    rc = lib().spike_awbm(n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp),
+                          perm.ctypes.data_as(i64p), None, None)
+    if rc:
+        raise HostError("spike_awbm failed (%d)" % rc)
+    return perm
 
 
 def fiedler_order(n, ia, ja, a):

@@ -200,3 +200,115 @@ def test_matcreatesubmatrixbanded_is_reference_rule(H, ):
         ko, fo, ib, jb, bb = O.band_extract(500, A.indptr, A.indices, A.data, kmax, frac)
         n, ia, ja, a = H.Mat(handle=B).csr()
         assert k.value == ko and f.value == fo and np.array_equal(ia, ib) and np.array_equal(ja, jb) and np.array_equal(a, bb)
+
+
+def _awbm_py(n, ia, ja, a):
+    """independent restatement of /root/reference/src/petsc_mat_awbm.c:42-205 in plain Python (small n only)"""
+    import math
+    eps = math.sqrt(np.finfo(float).eps)
+    amax = [max(abs(a[r]) for r in range(ia[c], ia[c + 1])) for c in range(n)]
+    w = [0.0] * len(a)
+    for c in range(n):
+        for r in range(ia[c], ia[c + 1]):
+            w[r] = float("inf") if a[r] == 0 else math.log(amax[c] / abs(a[r]))
+    u = [float("inf")] * n
+    for c in range(n):
+        for r in range(ia[c], ia[c + 1]):
+            u[ja[r]] = min(u[ja[r]], w[r])
+    v = [min(w[r] - u[ja[r]] for r in range(ia[c], ia[c + 1])) for c in range(n)]
+    match, matchR = [-1] * n, [-1] * n
+    for c in range(n):
+        for r in range(ia[c], ia[c + 1]):
+            if w[r] - u[ja[r]] - v[c] <= eps and matchR[ja[r]] < 0:
+                match[c], matchR[ja[r]] = ja[r], c
+                break
+    for tight in (True, False):
+        if not tight:
+            for c in range(n):
+                if match[c] >= 0:
+                    continue
+                for r in range(ia[c], ia[c + 1]):
+                    if matchR[ja[r]] < 0:
+                        match[c], matchR[ja[r]] = ja[r], c
+                        break
+        for c in range(n):
+            if match[c] >= 0:
+                continue
+            for r in range(ia[c], ia[c + 1]):
+                if tight and w[r] - u[ja[r]] - v[c] > eps:
+                    continue
+                c1 = matchR[ja[r]]
+                for r1 in range(ia[c1], ia[c1 + 1]):
+                    if matchR[ja[r1]] < 0 and (not tight or w[r1] - u[ja[r1]] - v[c1] <= eps):
+                        match[c], matchR[ja[r]] = ja[r], c
+                        match[c1], matchR[ja[r1]] = ja[r1], c1
+                        break
+                if match[c] >= 0:
+                    break
+    r = 0
+    for c in range(n):
+        if match[c] < 0:
+            while r < n:
+                if matchR[r] < 0:
+                    match[c], matchR[r] = r, c
+                    break
+                r += 1
+    p = [0] * n
+    for c in range(n):
+        p[match[c]] = c
+    return np.array(p)
+
+
+def test_awbm_matches_independent_restatement(H):
+    for seed, n in [(0, 40), (1, 150), (2, 400)]:
+        A = circuit_like(n, seed=seed).tocsr()
+        A.sort_indices()
+        p = H.awbm(n, A.indptr, A.indices, A.data)
+        assert sorted(p) == list(range(n))
+        assert np.array_equal(p, _awbm_py(n, list(A.indptr), list(A.indices), list(A.data)))
+        # B[i][j] = A[p[i]][j] has a zero-free diagonal (the matching is perfect on these matrices)
+        assert np.abs(A[p].diagonal()).min() > 0
+    import ctypes as C
+    L = H.lib()
+    H.chk(L.SpikePetscRegisterAll())
+    M = H.Mat.from_scipy(A)
+    r, c = C.c_void_p(), C.c_void_p()
+    H.chk(L.MatGetOrdering(M.h, b"awbm", C.byref(r), C.byref(c)))          # registered as in testbed2.c:67
+    assert np.array_equal(H.is_indices(r), p) and np.array_equal(H.is_indices(c), np.arange(n))
+
+
+def test_file_formats_roundtrip(H, tmp_path):
+    import ctypes as C
+    import struct
+    import scipy.io
+    L = H.lib()
+    A = circuit_like(200, seed=4).tocsr()
+    A.sort_indices()
+    # MatrixMarket written by scipy, read by the host library; and back
+    mm = str(tmp_path / "a.mtx")
+    scipy.io.mmwrite(mm, A, precision=17)
+    h = C.c_void_p()
+    H.chk(L.MatLoadMatrixMarket(mm.encode(), C.byref(h)))
+    assert abs(H.Mat(handle=h).to_scipy() - A).max() == 0
+    mm2 = str(tmp_path / "b.mtx")
+    H.chk(L.MatViewMatrixMarket(h, mm2.encode()))
+    assert abs(scipy.io.mmread(mm2).tocsr() - A).max() == 0
+    S = (A + A.T).tocsr()
+    scipy.io.mmwrite(str(tmp_path / "s.mtx"), S, symmetry="symmetric", precision=17)
+    hs = C.c_void_p()
+    H.chk(L.MatLoadMatrixMarket(str(tmp_path / "s.mtx").encode(), C.byref(hs)))
+    assert abs(H.Mat(handle=hs).to_scipy() - S).max() <= 1e-15
+    # PETSc binary AIJ written here from the format's definition (big-endian), read by MatLoad; and back
+    pb = str(tmp_path / "a.bin")
+    with open(pb, "wb") as f:
+        f.write(struct.pack(">4i", 1211216, 200, 200, A.nnz))
+        f.write(struct.pack(">%di" % 200, *np.diff(A.indptr)))
+        f.write(struct.pack(">%di" % A.nnz, *A.indices))
+        f.write(struct.pack(">%dd" % A.nnz, *A.data))
+    hb = C.c_void_p()
+    H.chk(L.MatLoad(pb.encode(), C.byref(hb)))
+    assert abs(H.Mat(handle=hb).to_scipy() - A).max() == 0
+    pb2 = str(tmp_path / "b.bin")
+    H.chk(L.MatViewBinary(hb, pb2.encode()))
+    assert open(pb, "rb").read() == open(pb2, "rb").read()
+    assert L.MatLoad(mm.encode(), C.byref(C.c_void_p())) != 0     # wrong format is an error, not a crash

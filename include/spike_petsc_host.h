@@ -112,6 +112,7 @@ PetscErrorCode MatGetOrdering_WBM(Mat A, MatOrderingType type, IS *row, IS *col)
 PetscErrorCode MatGetOrdering_AWBM(Mat A, MatOrderingType type, IS *row, IS *col);
 PetscErrorCode MatGetOrdering_Fiedler(Mat A, MatOrderingType type, IS *row, IS *col);
 PetscErrorCode MatGetOrdering_Natural(Mat A, MatOrderingType type, IS *row, IS *col);
+PetscErrorCode MatGetOrdering_RCM(Mat A, MatOrderingType type, IS *row, IS *col);
 
 /* PC */
 typedef PetscErrorCode (*PCCreateFn)(PC);
@@ -164,6 +165,7 @@ int spike_mc64_job5(int64_t n, const int64_t *colptr, const int64_t *rowind, con
                     double *u, double *v, int64_t *num);
 int spike_awbm(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, double *sr, double *sc);
 int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec);
+int spike_rcm_order(int64_t n, const int64_t *ia, const int64_t *ja, int64_t *order);
 int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
                             int64_t *bandwidth);
 

@@ -324,6 +324,20 @@ PetscErrorCode MatGetOrdering_WBM(Mat A, MatOrderingType type, IS *row, IS *col)
     free(perm);
     return e;
 }
+/* PETSc's built-in "rcm", used by the reference as second-stage ordering (src/HOWTO:2, src/testbed.c:236-284) */
+PetscErrorCode MatGetOrdering_RCM(Mat A, MatOrderingType type, IS *row, IS *col)
+{
+    (void)type;
+    const PetscInt n = A->n;
+    PetscInt *ord = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
+    if (spike_rcm_order(n, A->ia, A->ja, ord)) { free(ord); return seterr(PETSC_ERR_LIB, "RCM ordering failed"); }
+    PetscErrorCode e = ISCreateGeneral(n, ord, row);
+    free(ord);
+    if (e) return e;
+    ++(*row)->refct;
+    *col = *row;
+    return 0;
+}
 /* src/petsc_mat_awbm.c:42-225: row IS = p (p[match[c]] = c), column IS = identity (:200-205) */
 PetscErrorCode MatGetOrdering_AWBM(Mat A, MatOrderingType type, IS *row, IS *col)
 {
@@ -854,6 +868,7 @@ PetscErrorCode KSPReorderGetOrdering(KSP ksp, IS *row, IS *col)
 PetscErrorCode SpikePetscRegisterAll(void)
 {
     CHK(MatOrderingRegister("natural", MatGetOrdering_Natural));
+    CHK(MatOrderingRegister("rcm", MatGetOrdering_RCM));
     CHK(MatOrderingRegister("wbm", MatGetOrdering_WBM));         /* testbed2.c:66 */
     CHK(MatOrderingRegister("awbm", MatGetOrdering_AWBM));       /* :67 */
     CHK(MatOrderingRegister("fiedler", MatGetOrdering_Fiedler)); /* :68 */

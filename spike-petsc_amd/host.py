@@ -20,7 +20,7 @@ HOST_SYMBOLS = [
     "MatComputeBandwidth", "MatCreateSubMatrixBanded", "VecCreateSeq", "VecDestroy", "VecGetArray", "VecGetSize",
     "VecSet", "VecCopy", "VecAXPY", "VecNorm2", "VecPermute", "ISCreateGeneral", "ISCreateStride", "ISDestroy",
     "ISGetIndices", "MatOrderingRegister", "MatGetOrdering", "MatGetOrdering_WBM", "MatGetOrdering_AWBM", "MatGetOrdering_Fiedler",
-    "MatGetOrdering_Natural", "PCRegister", "PCCreate", "PCSetType", "PCSetOptionsPrefix", "PCAppendOptionsPrefix",
+    "MatGetOrdering_Natural", "MatGetOrdering_RCM", "spike_rcm_order", "PCRegister", "PCCreate", "PCSetType", "PCSetOptionsPrefix", "PCAppendOptionsPrefix",
     "PCSetOperators", "PCSetFromOptions", "PCSetUp", "PCApply", "PCReset", "PCDestroy", "PCView", "PCGetDiagonalScale",
     "PCCreate_Banded", "PCCreate_Spike", "PCCreate_None", "PCBandedSetMaxHalfBandwidth", "PCBandedSetNormFraction",
     "PCBandedGetInfo", "PCGetSpikeHandle", "KSPRegister", "KSPCreate", "KSPSetType", "KSPSetOptionsPrefix",
@@ -100,6 +100,7 @@ def lib():
     L.MatLoadMatrixMarket.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.MatViewMatrixMarket.argtypes = [vp, C.c_char_p]
     L.MatViewBinary.argtypes = [vp, C.c_char_p]
+    L.spike_rcm_order.argtypes = [i64, i64p, i64p, i64p]
     L.spike_fiedler_order.argtypes = [i64, i64p, i64p, dp, i64p, dp]
     L.spike_profile_bandwidth.argtypes = [i64, i64p, i64p, i64p, i64p, i64p]
     _L = L
@@ -209,6 +210,14 @@ def awbm(n, ia, ja, a):
     if rc:
         raise HostError("spike_awbm failed (%d)" % rc)
     return perm
+
+
+def rcm_order(n, ia, ja):
+    ia, ja = _i(ia), _i(ja)
+    order = np.zeros(n, dtype=np.int64)
+    if lib().spike_rcm_order(n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), order.ctypes.data_as(i64p)):
+        raise HostError("spike_rcm_order failed")
+    return order
 
 
 def fiedler_order(n, ia, ja, a):

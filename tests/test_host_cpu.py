@@ -312,3 +312,22 @@ def test_file_formats_roundtrip(H, tmp_path):
     H.chk(L.MatViewBinary(hb, pb2.encode()))
     assert open(pb, "rb").read() == open(pb2, "rb").read()
     assert L.MatLoad(mm.encode(), C.byref(C.c_void_p())) != 0     # wrong format is an error, not a crash
+
+
+def test_rcm_reduces_bandwidth_like_scipy(H):
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n, K = 3000, 5
+    rng = np.random.default_rng(3)
+    B = sp.diags([rng.uniform(0.2, 1, n - abs(d)) for d in range(-K, K + 1)], list(range(-K, K + 1))).tocsr()
+    q = rng.permutation(n)
+    A = B[q][:, q].tocsr(); A.sort_indices()
+    o = H.rcm_order(n, A.indptr, A.indices)
+    assert sorted(o) == list(range(n)) and np.array_equal(o, H.rcm_order(n, A.indptr, A.indices))
+    p0, b0 = H.profile_bandwidth(n, A.indptr, A.indices)
+    p1, b1 = H.profile_bandwidth(n, A.indptr, A.indices, o)
+    ps, bs = H.profile_bandwidth(n, A.indptr, A.indices, reverse_cuthill_mckee(A, symmetric_mode=False).astype(np.int64))
+    assert b1 <= 3 * K and b1 <= bs + K and b0 > 100 * K          # as good as scipy's RCM on a hidden band
+    # disconnected pattern: every vertex appears once, components stay contiguous
+    C2 = sp.block_diag([B[:50, :50], B[:30, :30], sp.eye(1)]).tocsr()
+    o = H.rcm_order(81, C2.indptr, C2.indices)
+    assert sorted(o) == list(range(81))

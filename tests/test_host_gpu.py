@@ -119,3 +119,29 @@ def test_config4_pipeline_mc64_fiedler_band_gmres(H, oracle):
     err2, its2, reason2, ksp2, _ = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=60, pc_type="none")
     assert reason2 != 2 or its2 > its
     H.chk(L.KSPDestroy(C.byref(ksp2)))
+
+
+def test_c_driver_testbed2_runs_the_reference_pipeline(H, tmp_path):
+    """examples/testbed2.c is the reference's driver (src/testbed2.c) written against the host mirror in C: run the
+    compiled program on a MatrixMarket file with the nested reorder options and read its 'Error in solution' line."""
+    import os
+    import subprocess
+    import scipy.io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "testbed2")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    n = 20000
+    A = circuit_like(n, seed=21)
+    path = str(tmp_path / "circuit.mtx")
+    scipy.io.mmwrite(path, A, precision=17)
+    cmd = [exe, "-mat", path, "-ksp_type", "reorder", "-mat_ordering_type", "wbm", "-mat_wbm_rows", "1",
+           "-reorder_ksp_type", "reorder", "-reorder_mat_ordering_type", "rcm",
+           "-reorder_reorder_ksp_type", "gmres", "-reorder_reorder_ksp_rtol", "1e-5", "-reorder_reorder_ksp_max_it", "500",
+           "-reorder_reorder_pc_type", "banded", "-reorder_reorder_banded_pc_spike_partitions", "8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float([l for l in out.stdout.splitlines() if l.startswith("Error in solution:")][0].split(":")[1])
+    its = int([l for l in out.stdout.splitlines() if l.startswith("Iterations:")][0].split()[1])
+    assert err <= 1e-3 * np.sqrt(n) and its <= 60
+    assert "reordering type = wbm" in out.stdout and "Banded: k =" in out.stdout and "SPIKE (MI355X)" in out.stdout

@@ -629,8 +629,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         double *dStat = nullptr;  // [absmax_in, absmax_out, probe absmax, extent(int)]
         HIPCHK(tmp.alloc(&dStat, 4));
         HIPCHK(hipMemsetAsync(dStat, 0, 4 * sizeof(double), st));
-        int nmin = h->chains[0].nrows;
-        for (int p = 1; p < P; ++p) nmin = std::min<int>(nmin, h->chains[p].nrows);
+        int nmin = h->chains[0].nrows, nmax = h->chains[0].nrows;
+        for (int p = 1; p < P; ++p) { nmin = std::min<int>(nmin, h->chains[p].nrows); nmax = std::max<int>(nmax, h->chains[p].nrows); }
         int extent = 0;
         if (h->spike_storage || h->S > 1) {
             for (int which = 0; which < 2; ++which) {
@@ -732,7 +732,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(hipMemcpyAsync(stat, dStat, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             // anything of weight left at the far edge of the window?  then the spikes do not decay: keep the re-solve variant
-            if (m < nmin && stat[1] > 1e3 * h->spike_tol * stat[0]) {
+            // (a window that covers every chain completely holds the full spikes: nothing to check)
+            if (m < nmax && stat[1] > 1e3 * h->spike_tol * stat[0]) {
                 (void)hipFree(h->dWf); (void)hipFree(h->dVf);
                 h->dWf = h->dVf = nullptr;
                 m = 0;

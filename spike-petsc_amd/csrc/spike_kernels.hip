@@ -37,7 +37,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 bool pick_cfg(int K, SweepCfg *cfg)
 {
     if (K < 0 || K > 256) return false;
-    if (K <= 8) *cfg = {8, 8, 1};
+    if (K <= 4) *cfg = {4, 4, 1};   // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8
+    else if (K <= 8) *cfg = {8, 8, 1};
     else if (K <= 16) *cfg = {16, 16, 1};
     else if (K <= 32) *cfg = {32, 32, 1};
     else { int nw = (K + 31) / 32; if (nw == 5) nw = 6; if (nw == 7) nw = 8; *cfg = {64, 32, nw}; }
@@ -198,6 +199,7 @@ static hipError_t launch_sweep_t(bool rev, int ngroups, const SweepArgs &a, hipS
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
 {
     if (ngroups <= 0) return hipSuccess;
+    if (cfg.R == 4) return launch_sweep_t<4, 4, 1>(rev, ngroups, a, st);
     if (cfg.R == 8) return launch_sweep_t<8, 8, 1>(rev, ngroups, a, st);
     if (cfg.R == 16) return launch_sweep_t<16, 16, 1>(rev, ngroups, a, st);
     if (cfg.R == 32) return launch_sweep_t<32, 32, 1>(rev, ngroups, a, st);
@@ -638,6 +640,7 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
     if (nchains <= 0 || maxsteps <= 0) return hipSuccess;
     dim3 grid((unsigned)maxsteps, (unsigned)nchains);
     switch (cfg.R) {
+    case 4: hipLaunchKernelGGL((k_pack<4>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 8: hipLaunchKernelGGL((k_pack<8>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 16: hipLaunchKernelGGL((k_pack<16>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 32: hipLaunchKernelGGL((k_pack<32>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
@@ -930,7 +933,7 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
 // y[a] = sum_c MT[c*K + a] * x[c];  IFT threads = nparts groups of KA lanes, partial sums via LDS.
 // 1024 threads per interface: the three dependent mat-vecs are latency-bound, so the only lever is loads in flight
 // (K/nparts = 16 sequential loads per thread at K = 128 instead of 64 with 256 threads).
-constexpr int IFT = 1024;
+constexpr int IFT = 1024;  // upper bound; narrow bands launch fewer threads (blockDim.x is what the kernel uses)
 __device__ __forceinline__ double iface_matvec(const double *MT, const double *xs, int K, int KA, int nparts, int a,
                                                int part, double *redb)
 {
@@ -954,9 +957,9 @@ __global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs
     const int tid = threadIdx.x;
     int KA = 1;
     while (KA < K) KA <<= 1;
-    const int nparts = IFT / KA;
+    const int nparts = (int)blockDim.x / KA;
     const int a = tid % KA, part = tid / KA;
-    for (int t = tid; t < K; t += IFT) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
+    for (int t = tid; t < K; t += (int)blockDim.x) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
     __syncthreads();
     // t = gt - W gb
     double s = iface_matvec(d.WT, gb, K, KA, nparts, a, part, redb);
@@ -987,7 +990,9 @@ __global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs
 hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st)
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(IFT), (size_t)4 * K * sizeof(double), st, K, ifs);
+    int nt = 64;
+    while (nt < IFT && nt < 8 * K) nt <<= 1;  // K = 128 -> 1024 threads, K <= 8 -> one wave
+    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs);
     return hipGetLastError();
 }
 

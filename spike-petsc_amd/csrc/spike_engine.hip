@@ -133,6 +133,7 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dHalo = nullptr;                              // matvec halo: [K left | K right]
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
+    double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
     // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
     int64_t op_n = 0, op_nnz = 0;
     int64_t *op_ia = nullptr;
@@ -267,6 +268,7 @@ static void free_factors(spike_handle h)
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
+    F(h->dAt);
     F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dHalo); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
@@ -959,7 +961,14 @@ static int matvec_dev(spike_handle h, const double *x, double *y)
     }
     hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh);
     HIPCHK(hipGetLastError());
-    HIPCHK(launch_band_matvec(h->n_global, h->row0, h->n, K, h->dA, h->ldA, h->dXh, y, st));
+    if (!h->dAt && h->ownA) {  // first mat-vec: make the tile-major copy (the library's own band has zeroed corners)
+        const size_t nblk = (size_t)((h->n + 127) / 128);
+        if (dalloc(&h->dAt, nblk * (size_t)(2 * K + 1) * 128) == hipSuccess)
+            HIPCHK(launch_band_to_tiles(h->n, K, h->dA, h->ldA, h->dAt, st));
+        else { h->dAt = nullptr; (void)hipGetLastError(); }  // no memory for the copy: stream the diagonal-major band
+    }
+    if (h->dAt) HIPCHK(launch_band_matvec_tiled(h->n, K, h->dAt, h->dXh, y, st));
+    else HIPCHK(launch_band_matvec(h->n_global, h->row0, h->n, K, h->dA, h->ldA, h->dXh, y, st));
     return SPIKE_OK;
 }
 

@@ -74,6 +74,8 @@ hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_
                            int64_t ld, hipStream_t st);
 hipError_t launch_band_matvec(int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
                               const double *xh, double *y, hipStream_t st);
+hipError_t launch_band_to_tiles(int64_t n, int K, const double *band, int64_t ld, double *At, hipStream_t st);
+hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const double *xh, double *y, hipStream_t st);
 // tips: rhs[row0+a] = block(a,b) for every chain (which: 0 = C at top rows of chains with has_top,
 // 1 = B at bottom rows of chains with has_bot); gather copies K rows of sol into column b of out.
 hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,

@@ -763,6 +763,62 @@ hipError_t launch_band_matvec(int64_t n_global, int64_t row0, int64_t n, int K, 
     return hipGetLastError();
 }
 
+// Tile-major copy of the band for the Krylov mat-vec: block b = 128 consecutive rows, inside it diagonal-major with two
+// adjacent rows per lane:  At[((b*(2K+1) + d)*64 + lane)*2 + e] = A[128 b + 2 lane + e, . + d - K].
+// A wave then streams ONE contiguous (2K+1) KiB region instead of 2K+1 regions that lie N*8 bytes apart
+// (one DRAM/TLB page each): 5.9 -> 6.6 TB/s at N = 4M, K = 128.  Rows past n are stored as zeros.
+__global__ __launch_bounds__(256) void k_band_to_tiles(int64_t n, int K, const double *band, int64_t ld, double *At)
+{
+    const int nd = 2 * K + 1;
+    const int64_t b = blockIdx.x;
+    for (int t = threadIdx.x; t < nd * 128; t += 256) {
+        const int d = t / 128, r = t % 128;  // r = 2*lane + e: consecutive threads -> consecutive rows of one diagonal
+        const int64_t i = b * 128 + r;
+        At[(b * nd + d) * 128 + r] = (i < n) ? band[(int64_t)d * ld + i] : 0.0;
+    }
+}
+
+hipError_t launch_band_to_tiles(int64_t n, int K, const double *band, int64_t ld, double *At, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_to_tiles, dim3((unsigned)((n + 127) / 128)), dim3(256), 0, st, n, K, band, ld, At);
+    return hipGetLastError();
+}
+
+// y = A x from the tile-major copy; a workgroup owns 512 rows (4 waves x 128 rows), x window in LDS as above
+__global__ __launch_bounds__(256) void k_band_matvec_tiled(int64_t n, int K, const double *At, const double *xh, double *y)
+{
+    extern __shared__ double xs[];  // 512 + 2K
+    const int64_t i0 = (int64_t)blockIdx.x * 512;
+    const int nw = 512 + 2 * K;
+    for (int t = threadIdx.x; t < nw; t += 256) xs[t] = (i0 + t < n + 2 * K) ? xh[i0 + t] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + w;
+    if (b * 128 >= n) return;
+    const int nd = 2 * K + 1;
+    const d2 *T = reinterpret_cast<const d2 *>(At) + b * nd * 64 + lane;
+    const double *xp = xs + w * 128 + 2 * lane;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int d = 0; d < nd; ++d) {
+        const d2 a = __builtin_nontemporal_load(T + (int64_t)d * 64);
+        s0 = fma(a.x, xp[d], s0);
+        s1 = fma(a.y, xp[d + 1], s1);
+    }
+    const int64_t i = b * 128 + 2 * lane;
+    if (i < n) y[i] = s0;
+    if (i + 1 < n) y[i + 1] = s1;
+}
+
+hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const double *xh, double *y, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_matvec_tiled, dim3((unsigned)((n + 511) / 512)), dim3(256), (size_t)(512 + 2 * K) * sizeof(double),
+                       st, n, K, At, xh, y);
+    return hipGetLastError();
+}
+
 // ---- spike tips by K pairs of sweeps (setup) -------------------------------------------------
 // C_p(a,b) = A[s+a, s-K+b]  -> band slot d = b - a        (a <= b)
 // B_p(a,b) = A[e-K+a, e+b]  -> band slot d = 2K + b - a   (b <= a)

@@ -455,12 +455,13 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
         else { (void)hipEventRecord(h->evs[h->nev].second, h->stream); ++h->nev; }
     };
     rec(true);
-    HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream));
+    const int tag = h->ready ? 0 : 1;  // setup (spike solves) vs PCApply: distinct kernel names in a trace
+    HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream, tag));
     rec(false);
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
-    HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream));
+    HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream, tag));
     rec(false);
     return SPIKE_OK;
 }

@@ -63,7 +63,7 @@ struct IfaceDesc {
 bool pick_cfg(int K, SweepCfg *cfg);
 
 // launchers (spike_kernels.hip)
-hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st);
+hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag = 0);
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st);
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,

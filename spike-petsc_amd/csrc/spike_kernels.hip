@@ -65,7 +65,9 @@ __device__ __forceinline__ int64_t tile_elem(int DPW, int lane, int d)
 //   backward: out = (D^{-1}U)^{-1} in
 // Bound: HBM.  Algorithmic bytes per row: KP*8 (tile) + 8 (in) + 8 (out) [+8 dinv forward].
 // ------------------------------------------------------------------------------------------
-template <int R, int DPW, int NW, bool REV>
+// TAG only names the instantiation: 0 = the sweeps of PCApply, 1 = the spike solves of setup (sub-ranges of the chains),
+// so that a kernel trace keeps the two populations apart.
+template <int R, int DPW, int NW, bool REV, int TAG>
 __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
 {
     constexpr int CPW = 64 / R;
@@ -189,26 +191,32 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
 }
 
 template <int R, int DPW, int NW>
-static hipError_t launch_sweep_t(bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
+static hipError_t launch_sweep_t(bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag)
 {
-    if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true>), dim3(ngroups), dim3(NW * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false>), dim3(ngroups), dim3(NW * 64), 0, st, a);
+    const dim3 g(ngroups), b(NW * 64);
+    if (tag == 0) {
+        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true, 0>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false, 0>), g, b, 0, st, a);
+    } else {
+        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true, 1>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false, 1>), g, b, 0, st, a);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
+hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag)
 {
     if (ngroups <= 0) return hipSuccess;
-    if (cfg.R == 4) return launch_sweep_t<4, 4, 1>(rev, ngroups, a, st);
-    if (cfg.R == 8) return launch_sweep_t<8, 8, 1>(rev, ngroups, a, st);
-    if (cfg.R == 16) return launch_sweep_t<16, 16, 1>(rev, ngroups, a, st);
-    if (cfg.R == 32) return launch_sweep_t<32, 32, 1>(rev, ngroups, a, st);
+    if (cfg.R == 4) return launch_sweep_t<4, 4, 1>(rev, ngroups, a, st, tag);
+    if (cfg.R == 8) return launch_sweep_t<8, 8, 1>(rev, ngroups, a, st, tag);
+    if (cfg.R == 16) return launch_sweep_t<16, 16, 1>(rev, ngroups, a, st, tag);
+    if (cfg.R == 32) return launch_sweep_t<32, 32, 1>(rev, ngroups, a, st, tag);
     switch (cfg.NW) {
-    case 2: return launch_sweep_t<64, 32, 2>(rev, ngroups, a, st);
-    case 3: return launch_sweep_t<64, 32, 3>(rev, ngroups, a, st);
-    case 4: return launch_sweep_t<64, 32, 4>(rev, ngroups, a, st);
-    case 6: return launch_sweep_t<64, 32, 6>(rev, ngroups, a, st);
-    case 8: return launch_sweep_t<64, 32, 8>(rev, ngroups, a, st);
+    case 2: return launch_sweep_t<64, 32, 2>(rev, ngroups, a, st, tag);
+    case 3: return launch_sweep_t<64, 32, 3>(rev, ngroups, a, st, tag);
+    case 4: return launch_sweep_t<64, 32, 4>(rev, ngroups, a, st, tag);
+    case 6: return launch_sweep_t<64, 32, 6>(rev, ngroups, a, st, tag);
+    case 8: return launch_sweep_t<64, 32, 8>(rev, ngroups, a, st, tag);
     }
     return hipErrorInvalidValue;
 }

@@ -110,6 +110,7 @@ struct spike_handle_s {
     std::vector<ChainDesc> chains;
     std::vector<GroupDesc> groups;
     int64_t ntiles = 0, maxsteps = 0;
+    size_t factor_doubles = 0;  // doubles of packed L factors (= of packed U factors) one sweep streams
     int nif = 0;
     // device buffers
     double *dA = nullptr;
@@ -380,6 +381,7 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
     int64_t minrows = (int64_t)16 * K;  // spikes of the synthetic dominant systems die out over ~10 K rows
     if (minrows < 512) minrows = 512;
     int64_t target = (int64_t)(2048 / cfg.NW) * cfg.CPW();  // ~8 waves on each of 256 CUs
+    if (cfg.scan) target = 8192;  // one light wave per chain: 32 waves per CU keep enough loads in flight
     int64_t byrows = n / minrows;
     int64_t P = target < byrows ? target : byrows;
     if (P > nblk) P = nblk;
@@ -456,12 +458,14 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     };
     rec(true);
     const int tag = h->ready ? 0 : 1;  // setup (spike solves) vs PCApply: distinct kernel names in a trace
-    HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream, tag));
+    if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, h->stream, tag));
+    else HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream, tag));
     rec(false);
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
-    HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream, tag));
+    if (h->cfg.scan) HIPCHK(launch_scan_sweep(true, h->P, a, h->stream, tag));
+    else HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream, tag));
     rec(false);
     return SPIKE_OK;
 }
@@ -586,7 +590,9 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
     HIPCHK(launch_factor(dLU, n, K, h->dChains, P, boost, dNb, st));
-    const size_t tile_total = (size_t)h->ntiles * (size_t)cfg.tile_doubles();
+    // scan path (K = 1): "tiles" are plain per-row arrays, dLt = l, dUt = c
+    const size_t tile_total = cfg.scan ? (size_t)n : (size_t)h->ntiles * (size_t)cfg.tile_doubles();
+    h->factor_doubles = tile_total;
     HIPCHK(dalloc(&h->dLt, tile_total));
     HIPCHK(dalloc(&h->dUt, tile_total));
     HIPCHK(dalloc(&h->dDinv, (size_t)n));
@@ -594,7 +600,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(dalloc(&h->dTmp, (size_t)n));
     HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
     HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
-    HIPCHK(launch_pack(cfg, dLU, n, K, h->dChains, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
+    if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChains, P, h->dLt, h->dUt, h->dDinv, st));
+    else HIPCHK(launch_pack(cfg, dLU, n, K, h->dChains, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
     unsigned long long nb = 0;
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -672,7 +679,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (m > nmin) m = nmin;
             // worth it only while the correction stays well below a pass over the factors
             const double corr_bytes = 2.0 * m * (double)K * 8.0 * P;
-            const double pass_bytes = 2.0 * (double)h->ntiles * (double)cfg.tile_doubles() * 8.0;
+            const double pass_bytes = 2.0 * (double)h->factor_doubles * 8.0;
             if (corr_bytes > 0.85 * pass_bytes) m = 0;  // 1 + corr/pass passes against 2 for re-solving
         }
         if (m > 0) {
@@ -998,7 +1005,7 @@ extern "C" int spike_measure_read_bw(spike_handle h, int reps, double *gbps)
 {
     if (!h || !gbps || reps < 1) return SPIKE_ERR_ARG;
     if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_measure_read_bw needs a setup");
-    const int64_t nd = h->ntiles * h->cfg.tile_doubles();
+    const int64_t nd = (int64_t)h->factor_doubles;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(launch_read_bw(h->dLt, nd, h->dY, h->stream));  // warm-up
@@ -1230,7 +1237,7 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->chains_local = h->P;
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
     o->nboost = h->nboost;
-    o->factor_bytes = (int64_t)(2 * (size_t)h->ntiles * (size_t)h->cfg.tile_doubles() + (size_t)h->n) * 8;
+    o->factor_bytes = (int64_t)(2 * h->factor_doubles + (size_t)h->n) * 8;
     o->iface_bytes = (int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) * (int64_t)h->K * h->K * 8;
     o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;

@@ -27,7 +27,8 @@ struct SweepCfg {
     int R;    // rows per block (8,16,32,64)
     int DPW;  // diagonals per wave (= tile entries per lane per wave)
     int NW;   // waves per chain
-    int KP() const { return DPW * NW; }
+    bool scan = false;  // K = 1: no tiles, one multiplier per row, wavefront scan (k_scan_sweep)
+    int KP() const { return scan ? 1 : DPW * NW; }
     int CPW() const { return 64 / R; }
     int64_t tile_doubles() const { return (int64_t)NW * DPW * 64; }
 };
@@ -69,6 +70,10 @@ hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains,
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
                        const GroupDesc *groups, int nchains, int64_t total_blocks, const int64_t *blk_prefix,
                        double *Lt, double *Ut, double *dinv, hipStream_t st);
+// tridiagonal path: LU band -> l[i] = L[i,i-1], c[i] = U[i,i+1]/U[i,i], dinv[i] = 1/U[i,i]; and the scan sweeps
+hipError_t launch_pack_scan(const double *lu, int64_t ld, const ChainDesc *chains, int nchains, double *l, double *c,
+                            double *dinv, hipStream_t st);
+hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag = 0);
 hipError_t launch_absmax_diag(const double *band, int64_t ld, int K, int64_t n, double *out, hipStream_t st);
 hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
                            int64_t ld, hipStream_t st);

@@ -37,7 +37,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 bool pick_cfg(int K, SweepCfg *cfg)
 {
     if (K < 0 || K > 256) return false;
-    if (K <= 4) *cfg = {4, 4, 1};   // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8
+    if (K == 1) { *cfg = {64, 2, 1}; cfg->scan = true; }  // tridiagonal: wavefront scan, 56 bytes per row and pass
+    else if (K <= 4) *cfg = {4, 4, 1};   // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8
     else if (K <= 8) *cfg = {8, 8, 1};
     else if (K <= 16) *cfg = {16, 16, 1};
     else if (K <= 32) *cfg = {32, 32, 1};
@@ -219,6 +220,100 @@ hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepA
     case 8: return launch_sweep_t<64, 32, 8>(rev, ngroups, a, st, tag);
     }
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan_sweep: the narrow-band (K = 1) solve as a WAVEFRONT-LEVEL SCAN.  A first-order recurrence
+//   forward  g_i = f_i - l_i g_{i-1},   backward  x_i = y_i - c_i x_{i+1}
+// is the composition of affine maps  t -> a_i t + b_i; 64 consecutive rows sit on the 64 lanes of a wave, an inclusive
+// scan of the maps (6 shuffle steps) resolves the whole segment at once, and one carry links the segments of a chain.
+// One wave per chain, eight 64-row segments in flight per iteration.  HBM-bound: 32 B/row forward (l, f, 1/u, y),
+// 24 B/row backward (c, y, x) -- against 104 B/row when a tridiagonal system is streamed as 4-diagonal tiles.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine_scan64(double &a, double &b, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double au = __shfl_up(a, off), bu = __shfl_up(b, off);
+        if (lane >= off) { b = fma(a, bu, b); a *= au; }
+    }
+}
+
+template <bool REV, int TAG>
+__global__ __launch_bounds__(256) void k_scan_sweep(SweepArgs s)
+{
+    constexpr int U = 8;  // segments per iteration
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= s.nchains) return;
+    const ChainDesc cd = s.chains[p];
+    const double *coef = s.tiles;
+    const int nseg = (cd.nrows + 63) / 64;
+    double carry = 0.0;
+    for (int sg = 0; sg < nseg; sg += U) {
+        double a[U], b[U], dv[U];
+        int64_t gi[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = (sg + u) * 64 + lane;           // position in sweep order
+            const int rl = REV ? cd.nrows - 1 - q : q;    // local row
+            act[u] = (sg + u < nseg) && q < cd.nrows;
+            gi[u] = cd.row0 + rl;
+            a[u] = act[u] ? -coef[gi[u]] : 0.0;
+            b[u] = act[u] ? s.in[gi[u]] : 0.0;
+            dv[u] = 1.0;
+            if (!REV) {
+                if (act[u]) dv[u] = s.dinv[gi[u]];
+                if (s.corr_top != nullptr && act[u]) {   // K = 1: one corrected row at each end of the chain
+                    if (rl == 0) b[u] -= s.corr_top[p];
+                    if (rl == cd.nrows - 1) b[u] -= s.corr_bot[p];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) affine_scan64(a[u], b[u], lane);  // independent of the carry: overlaps across u
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double g = fma(a[u], carry, b[u]);
+            carry = __shfl(g, 63);
+            if (act[u]) s.out[gi[u]] = REV ? g : g * dv[u];
+        }
+    }
+}
+
+hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag)
+{
+    if (nchains <= 0) return hipSuccess;
+    const dim3 g((nchains + 3) / 4), b(256);
+    if (tag == 0) {
+        if (rev) hipLaunchKernelGGL((k_scan_sweep<true, 0>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_scan_sweep<false, 0>), g, b, 0, st, a);
+    } else {
+        if (rev) hipLaunchKernelGGL((k_scan_sweep<true, 1>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_scan_sweep<false, 1>), g, b, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+__global__ void k_pack_scan(const double *lu, int64_t ld, const ChainDesc *chains, double *l, double *c, double *dinv)
+{
+    const ChainDesc cd = chains[blockIdx.y];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x) {
+        const int64_t i = cd.row0 + r;
+        const double di = 1.0 / lu[ld + i];                    // K = 1: diagonals 0 (sub), 1 (main), 2 (super)
+        dinv[i] = di;
+        l[i] = (r > 0) ? lu[i] : 0.0;                          // multipliers stop at the chain start
+        c[i] = (r < cd.nrows - 1) ? lu[2 * ld + i] * di : 0.0; // and the super-diagonal at its end
+    }
+}
+
+hipError_t launch_pack_scan(const double *lu, int64_t ld, const ChainDesc *chains, int nchains, double *l, double *c,
+                            double *dinv, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_scan, dim3(8, nchains), dim3(256), 0, st, lu, ld, chains, l, c, dinv);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -276,3 +276,19 @@ def test_edge_sizes(spike, oracle, torch_cuda, N, K, P):
     f = oracle.gen_vec(N)
     sp = spike.Spike(partitions=P).setup_band(band)
     assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-13
+
+
+@pytest.mark.parametrize("N,K,P", [(8192, 16, 4), (8192, 40, 4), (16384, 128, 2), (16384, 200, 2)])
+def test_pivot_boost_in_the_blocked_mfma_factorisation(spike, oracle, torch_cuda, N, K, P):
+    """rows whose diagonal and sub-diagonal entries are zero produce an exactly zero pivot; the blocked (MFMA) LU must
+    boost the same pivots as the oracle's scalar LU and give the same preconditioner"""
+    band = oracle.gen_band(N, K)
+    for i in (777, N // 2 + 5, N - 300):
+        band[:K + 1, i] = 0.0
+    ref = oracle.Spike(band, P, boost_rel=1e-3)   # a mild boost keeps the boosted factors well conditioned
+    sp = spike.Spike(partitions=P, boost=1e-3)
+    sp.set_option("subsplit", "off")
+    sp.setup_band(band)
+    assert sp.info().nboost == ref.nboost >= 3
+    f = oracle.gen_vec(N)
+    assert _rel(sp.apply(f), ref.apply(f, 1)) <= 1e-7   # 1/boost amplifies rounding differences of the two LU orders

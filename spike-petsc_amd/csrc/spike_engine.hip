@@ -132,7 +132,6 @@ struct spike_handle_s {
     int nif_int = 0;
     int spike_m = 0;                                      // rows kept per spike (0 = re-solve variant)
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
-    double *dHalo = nullptr;                              // matvec halo: [K left | K right]
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
     // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
@@ -150,7 +149,6 @@ struct spike_handle_s {
     int k_extracted = -1;
     double frac_extracted = 0.0;
     // profiling of the sweep kernels
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
     int nev = 0;
 };
@@ -270,7 +268,7 @@ static void free_factors(spike_handle h)
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dAt);
-    F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dHalo); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
+    F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
     h->chains.clear();
@@ -756,7 +754,6 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 1, h->dBT, st));
 
         // interface i (local numbering): upper chain = i, lower chain = i+1; rank boundaries appended
-        std::vector<double *> Wsrc(nif), Vsrc(nif);
         double *dWif = nullptr, *dVif = nullptr, *dWork = nullptr;
         int *dFlag = nullptr;
         HIPCHK(tmp.alloc(&dWif, (size_t)nif * kk));

@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ksp", action="store_true")
     ap.add_argument("--ksp-iters", type=int, default=30)
+    ap.add_argument("--ksp-delta", type=float, default=1.0,
+                    help="second KSP measurement on the operator with this diagonal dominance (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -202,6 +204,27 @@ def main():
                     "error_inf": float((xg - u).abs().max()),
                     "note": "iters_per_sec = steady-state rate over a fixed number of left-preconditioned GMRES(30) "
                             "iterations (rtol 0); the solve to rtol 1e-5 (src/makefile:18) needs converged_iters iterations"})
+
+    # The same Krylov loop on an operator the preconditioner does NOT invert exactly (the usual case: PC built from a
+    # nearby matrix): A' = the same off-diagonals with diagonal dominance --ksp-delta instead of --delta.
+    if ksp is not None and args.ksp_delta > 0:
+        opband = S.gen_band_device(N, K, seed=12345, delta=args.ksp_delta, row0=r0, nrows=n_local)
+        sp.set_operator_band(opband)
+        del opband
+        b2 = sp.operator_matvec(u)
+        xg.zero_()
+        barrier()
+        itp, rnp, msp, okp = sp.gmres(b2, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
+        barrier()
+        tk = torch.tensor([msp], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        xg.zero_()
+        itc, rnc, msc, okc = sp.gmres(b2, xg, restart=30, rtol=1e-5, maxit=500)
+        ksp["nearby_operator"] = {"operator_delta": args.ksp_delta, "iters": itp, "solve_ms": float(tk.item()),
+                                  "iters_per_sec": itp / (float(tk.item()) * 1e-3), "converged_iters_rtol1e-5": itc,
+                                  "converged": bool(okc), "error_inf": float((xg - u).abs().max())}
+        sp.set_operator_band(None)
 
     if rank == 0:
         out = {

@@ -138,6 +138,11 @@ int spike_gmres(spike_handle h, const double *b, double *x, int restart, double 
  * (then spike_gmres needs use_pc = 0).  Single rank.                                              */
 int spike_set_operator_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a);
 int spike_clear_operator(spike_handle h);
+/* A BANDED operator different from the matrix given at setup (same n_local, K, row block; device, diagonal-major;
+ * copied at once, NULL clears): the preconditioner-from-a-nearby-matrix case.  Out-of-range corner slots must be 0. */
+int spike_set_operator_band(spike_handle h, const double *band_dev, int64_t ld);
+/* y = Op x with the operator spike_gmres uses (CSR operator > banded operator > band kept at setup); device pointers */
+int spike_operator_matvec(spike_handle h, const double *x, double *y);
 
 /* raw device memory for C hosts that have no HIP headers (the host mirror uses these) */
 int spike_dev_malloc(void **p, size_t bytes);

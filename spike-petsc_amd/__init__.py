@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "spike_band_matvec", "spike_gen_band", "spike_get_info", "spike_view", "spike_get_tips", "spike_last_sweep_ms",
     "spike_set_operator_csr", "spike_clear_operator", "spike_dev_malloc", "spike_dev_free", "spike_dev_upload",
     "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band", "spike_measure_read_bw",
+    "spike_set_operator_band", "spike_operator_matvec",
 ]
 
 
@@ -98,6 +99,8 @@ def lib():
     L.spike_view.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.spike_get_tips.argtypes = [vp, dptr, dptr]
     L.spike_last_sweep_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.spike_set_operator_band.argtypes = [vp, vp, i64]
+    L.spike_operator_matvec.argtypes = [vp, vp, vp]
     L.spike_measure_read_bw.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.spike_csr_band_k.argtypes = [i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                    C.POINTER(C.c_double)]
@@ -211,6 +214,19 @@ class Spike:
         import torch
         y = torch.empty_like(x) if y is None else y
         self._chk(self.L.spike_band_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
+    def set_operator_band(self, band):
+        """banded operator != preconditioner matrix (torch CUDA tensor [2K+1, n]); None clears"""
+        if band is None:
+            self._chk(self.L.spike_set_operator_band(self.h, None, 0))
+        else:
+            self._chk(self.L.spike_set_operator_band(self.h, C.c_void_p(band.data_ptr()), band.shape[1]))
+
+    def operator_matvec(self, x, y=None):
+        import torch
+        y = torch.empty_like(x) if y is None else y
+        self._chk(self.L.spike_operator_matvec(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
         return y
 
     def gmres(self, b, x, restart=30, rtol=1e-5, maxit=500, use_pc=True):

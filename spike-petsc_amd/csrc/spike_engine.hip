@@ -134,7 +134,9 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
+    double *dAtOp = nullptr;                              // tile-major copy of a separate banded operator (spike_set_operator_band)
     // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
+    bool use_kept_band = false;  // spike_band_matvec: bypass the optional operators
     int64_t op_n = 0, op_nnz = 0;
     int64_t *op_ia = nullptr;
     int32_t *op_ja = nullptr;
@@ -267,7 +269,7 @@ static void free_factors(spike_handle h)
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
-    F(h->dAt);
+    F(h->dAt); F(h->dAtOp);
     F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
@@ -371,6 +373,8 @@ extern "C" int spike_comm_init_local(spike_handle h, int nranks, int rank, int g
     h->lcomm = c;
     return SPIKE_OK;
 }
+
+static int matvec_dev(spike_handle h, const double *x, double *y);
 
 // ---- partitioning ------------------------------------------------------------------------------------
 static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
@@ -966,6 +970,10 @@ static int matvec_dev(spike_handle h, const double *x, double *y)
     }
     hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh);
     HIPCHK(hipGetLastError());
+    if (h->dAtOp && !h->use_kept_band) {
+        HIPCHK(launch_band_matvec_tiled(h->n, K, h->dAtOp, h->dXh, y, st));
+        return SPIKE_OK;
+    }
     if (!h->dAt && h->ownA) {  // first mat-vec: make the tile-major copy (the library's own band has zeroed corners)
         const size_t nblk = (size_t)((h->n + 127) / 128);
         if (dalloc(&h->dAt, nblk * (size_t)(2 * K + 1) * 128) == hipSuccess)
@@ -982,8 +990,10 @@ extern "C" int spike_band_matvec(spike_handle h, const double *x, double *y)
     if (!h || !x || !y) return SPIKE_ERR_ARG;
     if (!h->ready || !h->dA) return fail(h, SPIKE_ERR_STATE, "spike_band_matvec needs a setup with the band kept");
     const int64_t keep = h->op_n;
-    h->op_n = 0;  // the band, not the optional CSR operator
+    h->op_n = 0;  // the band kept at setup, not an optional operator
+    h->use_kept_band = true;
     const int rc = matvec_dev(h, x, y);
+    h->use_kept_band = false;
     h->op_n = keep;
     return rc;
 }
@@ -1175,6 +1185,31 @@ extern "C" int spike_set_operator_csr(spike_handle h, int64_t n, const int64_t *
     const double avg = (double)nnz / (double)n;
     h->op_tpr = avg > 48 ? 64 : avg > 12 ? 16 : avg > 3 ? 4 : 1;
     return SPIKE_OK;
+}
+
+// A banded operator that differs from the preconditioner's matrix (same n, K, row block): the usual situation of a
+// preconditioner built from a nearby or lagged matrix.  band_dev: device, diagonal-major; copied (tile-major) at once.
+extern "C" int spike_set_operator_band(spike_handle h, const double *band_dev, int64_t ld)
+{
+    if (!h) return SPIKE_ERR_ARG;
+    if (!band_dev) {  // clear
+        (void)hipStreamSynchronize(h->stream);
+        if (h->dAtOp) { (void)hipFree(h->dAtOp); h->dAtOp = nullptr; }
+        return SPIKE_OK;
+    }
+    if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_set_operator_band needs a setup (it takes n and K from it)");
+    if (ld < h->n) return fail(h, SPIKE_ERR_ARG, "ld < n_local");
+    if (!h->dAtOp) HIPCHK(dalloc(&h->dAtOp, (size_t)((h->n + 127) / 128) * (size_t)(2 * h->K + 1) * 128));
+    HIPCHK(launch_band_to_tiles(h->n, h->K, band_dev, ld, h->dAtOp, h->stream));
+    return SPIKE_OK;
+}
+
+// y = Op x with the operator spike_gmres would use (CSR operator, banded operator, or the band kept at setup)
+extern "C" int spike_operator_matvec(spike_handle h, const double *x, double *y)
+{
+    if (!h || !x || !y) return SPIKE_ERR_ARG;
+    if (h->op_n == 0 && (!h->ready || !h->dA)) return fail(h, SPIKE_ERR_STATE, "no operator");
+    return matvec_dev(h, x, y);
 }
 
 extern "C" int spike_dev_malloc(void **p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 8) == hipSuccess ? SPIKE_OK : SPIKE_ERR_NOMEM; }

@@ -292,3 +292,25 @@ def test_pivot_boost_in_the_blocked_mfma_factorisation(spike, oracle, torch_cuda
     assert sp.info().nboost == ref.nboost >= 3
     f = oracle.gen_vec(N)
     assert _rel(sp.apply(f), ref.apply(f, 1)) <= 1e-7   # 1/boost amplifies rounding differences of the two LU orders
+
+
+def test_gmres_on_a_nearby_banded_operator(spike, oracle, torch_cuda):
+    """the preconditioner is built from A (delta 1.2), the Krylov solve runs on A' (delta 1.0, same off-diagonals):
+    spike_set_operator_band + spike_gmres must solve A' x = b, and take more than one iteration"""
+    torch = torch_cuda
+    N, K, P = 32768, 24, 16
+    A = oracle.gen_band(N, K, delta=1.2)
+    A2 = oracle.gen_band(N, K, delta=1.0)
+    u = oracle.gen_vec(N, seed=3)
+    sp = spike.Spike(partitions=P).setup_band(A)
+    sp.set_operator_band(torch.from_numpy(A2).cuda())
+    b2 = sp.operator_matvec(torch.from_numpy(u).cuda())
+    assert _rel(b2.cpu().numpy(), oracle.band_matvec(A2, u)) <= 1e-14
+    x = torch.zeros(N, dtype=torch.float64, device="cuda")
+    it, rn, ms, ok = sp.gmres(b2, x, restart=30, rtol=1e-10, maxit=200)
+    assert ok and 2 <= it <= 60
+    assert _rel(x.cpu().numpy(), u) <= 1e-7
+    xo, ito, *_ = oracle.gmres(A2, oracle.band_matvec(A2, u), oracle.Spike(A, P), variant=1, rtol=1e-10, maxit=200)
+    assert abs(it - ito) <= 1
+    sp.set_operator_band(None)
+    assert _rel(sp.matvec(torch.from_numpy(u).cuda()).cpu().numpy(), oracle.band_matvec(A, u)) <= 1e-14

@@ -134,6 +134,7 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
+    double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     double *dAtOp = nullptr;                              // tile-major copy of a separate banded operator (spike_set_operator_band)
     // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
     bool use_kept_band = false;  // spike_band_matvec: bypass the optional operators
@@ -269,7 +270,7 @@ static void free_factors(spike_handle h)
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
-    F(h->dAt); F(h->dAtOp);
+    F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
     F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
     h->gm_restart = 0;
     h->ready = false;
@@ -926,14 +927,14 @@ extern "C" int spike_apply(spike_handle h, const double *x, double *y, int on_de
     if (!h || !x || !y || x == y) return fail(h, SPIKE_ERR_ARG, "spike_apply: bad pointers (x must differ from y)");
     if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_apply before setup");
     if (on_device) return apply_dev(h, x, y);
-    TmpPool tmp;
-    double *dx = nullptr, *dy = nullptr;
-    HIPCHK(tmp.alloc(&dx, (size_t)h->n));
-    HIPCHK(tmp.alloc(&dy, (size_t)h->n));
-    HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
-    const int rc = apply_dev(h, dx, dy);
+    // host vectors: staged through two device buffers that live as long as the factors (a Krylov method calls this
+    // once per iteration; PCIe moves 2*n*8 bytes per call)
+    if (!h->dStageX) HIPCHK(dalloc(&h->dStageX, (size_t)h->n));
+    if (!h->dStageY) HIPCHK(dalloc(&h->dStageY, (size_t)h->n));
+    HIPCHK(hipMemcpyAsync(h->dStageX, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    const int rc = apply_dev(h, h->dStageX, h->dStageY);
     if (rc != SPIKE_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
-    HIPCHK(hipMemcpyAsync(y, dy, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(y, h->dStageY, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return SPIKE_OK;
 }

@@ -1,4 +1,6 @@
-import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),"tests"))
+"""BASELINE config 4 at ASIC_320k scale on the circuit-like stand-in: times MC64, Fiedler, RCM and the nested-reorder KSP
+(run on the GPU box: python tools/config4_timing.py).  Numbers quoted in DESIGN.md section 4."""
+import sys, os, time; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, ctypes as C, torch
 import spike_petsc_amd.host as H
 from matrices import circuit_like

@@ -187,10 +187,14 @@ static hipError_t dalloc(T **p, size_t count)
     return hipMalloc((void **)p, count * sizeof(T));
 }
 
+// true when the exchange steps must run: several ranks, or the one-rank RCCL self-test (spike_comm_init with nranks = 1
+// and SPIKE_RCCL_SELFTEST=1 creates a real one-rank communicator so that every RCCL call site runs on one GPU)
+static inline bool exchanging(const spike_handle_s *h) { return h->nranks > 1 || h->comm != nullptr; }
+
 // ---- collectives: RCCL, or the loopback transport -------------------------------------------------
 static int coll_allgather(spike_handle h, const double *send, double *recv, size_t count)
 {
-    if (h->nranks == 1) return SPIKE_OK;
+    if (!exchanging(h)) return SPIKE_OK;
     if (h->lcomm) {
         LocalComm &c = *h->lcomm;
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -208,7 +212,7 @@ static int coll_allgather(spike_handle h, const double *send, double *recv, size
 
 static int coll_allreduce(spike_handle h, double *buf, size_t count, int op)
 {
-    if (h->nranks == 1) return SPIKE_OK;
+    if (!exchanging(h)) return SPIKE_OK;
     if (h->lcomm) {
         LocalComm &c = *h->lcomm;
         std::vector<double> mine(count);
@@ -352,7 +356,8 @@ extern "C" int spike_comm_init(spike_handle h, int nranks, int rank, const char 
     if (h->ready) return fail(h, SPIKE_ERR_STATE, "spike_comm_init must precede setup");
     h->nranks = nranks;
     h->rank = rank;
-    if (nranks == 1) return SPIKE_OK;
+    const char *selftest = getenv("SPIKE_RCCL_SELFTEST");
+    if (nranks == 1 && !(selftest && selftest[0] == '1' && id)) return SPIKE_OK;
     if (!id) return SPIKE_ERR_ARG;
     if (!rccl_load()) return fail(h, SPIKE_ERR_COMM, "cannot load librccl: %s", dlerror());
     ncclUniqueId_ u;
@@ -613,7 +618,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     tmp.release(dScal);
 
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
-    const bool multi = h->nranks > 1;
+    const bool multi = exchanging(h);
     const int nif_local = P - 1;
     const int nif = (K > 0) ? nif_local + (multi && h->rank > 0 ? 1 : 0) + (multi && h->rank < h->nranks - 1 ? 1 : 0) : 0;
     h->nif = nif;
@@ -666,7 +671,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         if (h->S > 1) {
             // do the spikes die (below spike_tol of their peak) before they reach the far end of the shortest chain?
             double bad = ((int64_t)(extent * 1.06) + K > nmin) ? 1.0 : 0.0;
-            if (h->nranks > 1) {  // every rank must take the same decision (the redo below is collective)
+            if (exchanging(h)) {  // every rank must take the same decision (the redo below is collective)
                 HIPCHK(hipMemcpyAsync(dStat + 2, &bad, sizeof(double), hipMemcpyHostToDevice, st));
                 if ((rc = coll_allreduce(h, dStat + 2, 1, NCCL_MAX))) return rc;
                 HIPCHK(hipMemcpyAsync(&bad, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -896,7 +901,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     const bool coupled = h->variant == SPIKE_VARIANT_COUPLED;
     const int nif = coupled ? h->nif : h->nif_int;  // decoupled: only the cuts inside the caller's partitions
     if (nif > 0) {
-        const bool multi = coupled && h->nranks > 1;
+        const bool multi = coupled && exchanging(h);
         const int K = h->K, P = h->P;
         hipLaunchKernelGGL(k_gather_tips, dim3(P), dim3(64), 0, st, y, K, h->dChains, P, h->dTips, multi ? h->dSend : nullptr);
         HIPCHK(hipGetLastError());
@@ -964,7 +969,7 @@ static int matvec_dev(spike_handle h, const double *x, double *y)
     }
     const int K = h->K;
     if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
-    const bool multi = h->nranks > 1;
+    const bool multi = exchanging(h);
     if (multi && K > 0) {
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, x, h->n, K, h->dSend);
         { int rc2 = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K); if (rc2) return rc2; }

@@ -87,7 +87,7 @@ const char *spike_last_error(spike_handle h);
 /* keys: "partitions" (int >=1, or 0 = auto), "variant" ("decoupled"|"coupled"|0|1),
  *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1),
  *       "spike_storage" ("auto"|"off": keep the spikes' decayed part and apply the coupled variant in ONE pass
- *        when they are short, else/off: second pass over the factors), "spike_tol" (relative drop level, 1e-17),
+ *        when they are short, else/off: second pass over the factors), "spike_tol" (relative drop level, 1e-16),
  *       "subsplit" ("auto"|"off": a caller-chosen partition count is honoured, but each partition may be swept as
  *        several chains when setup MEASURES that the spikes die inside a chain, which leaves the preconditioner
  *        unchanged to rounding; off: exactly one chain per partition),

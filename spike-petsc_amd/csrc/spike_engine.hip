@@ -94,7 +94,7 @@ struct spike_handle_s {
     int profile = 0;
     int subsplit = 1;           // 1 = cut a caller-chosen partition into sub-chains when the spikes provably die inside them
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
-    double spike_tol = 1e-17;   // relative magnitude below which spike rows are dropped
+    double spike_tol = 1e-16;   // relative magnitude below which spike rows are dropped (fp64 rounding level)
     hipStream_t stream = nullptr;
     std::string err;
     // communicator

@@ -10,6 +10,8 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_mc64_reference_known_answer_fixture():
+    from conftest import _ensure_built
+    _ensure_built()
     import spike_petsc_amd.host as H
     d = json.load(open(os.path.join(G, "mc64_wbm_3x3.json")))
     perm, u, v, num = H.mc64_job5(d["n"], d["ia"], d["ja"], d["a"])

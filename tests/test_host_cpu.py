@@ -15,6 +15,8 @@ from matrices import circuit_like
 
 @pytest.fixture(scope="module")
 def H():
+    from conftest import _ensure_built
+    _ensure_built()
     import spike_petsc_amd.host as H
     H.lib()
     return H

@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 def H():
     import torch
     assert torch.cuda.is_available()
+    from conftest import _ensure_built
+    _ensure_built()
     import spike_petsc_amd.host as H
     H.chk(H.lib().SpikePetscRegisterAll())
     return H

@@ -23,7 +23,7 @@ def build(native=False):
         out = os.path.join(_HERE, "liboracle_native.so")
         subprocess.check_call(
             ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", out,
-             os.path.join(_HERE, "spike_oracle.c"), os.path.join(_HERE, "mc64_oracle.c"), "-lm"])
+             os.path.join(_HERE, "spike_oracle.c"), "-lm"])
         return out
     subprocess.check_call(["make", "-s", "-C", _HERE])
     return os.path.join(_HERE, "liboracle.so")

@@ -124,7 +124,6 @@ struct spike_handle_s {
     double *dWT = nullptr, *dVT = nullptr, *dST = nullptr;  // per interface, column-major
     double *dBT = nullptr, *dCT = nullptr;                // per chain, column-major
     double *dCorrTop = nullptr, *dCorrBot = nullptr;      // per chain, K
-    double *dTips = nullptr;                              // per chain [gt(K) | gb(K)]
     double *dWf = nullptr, *dVf = nullptr;                // stored spikes, per chain column-major K x m
     double *dXb = nullptr, *dXt = nullptr;                // tip solutions, (P+2) x K (slot p+1 = chain p)
     IfaceDesc *dIfsFast = nullptr;
@@ -144,8 +143,10 @@ struct spike_handle_s {
     double *op_a = nullptr;
     int op_tpr = 1;
     // gmres workspace
-    double *dV = nullptr, *dW = nullptr, *dZ = nullptr, *dDots = nullptr, *dCoef = nullptr;
+    double *dV = nullptr, *dW = nullptr, *dZ = nullptr, *dDots = nullptr, *dCoef = nullptr, *dRedWs = nullptr;
     int gm_restart = 0;
+    int64_t gm_ldv = 0;
+    int cgs_refine = 0;  // 0 never (PETSc's default for -ksp_type gmres), 1 ifneeded, 2 always
     // info
     int64_t nboost = 0;
     double setup_ms = 0.0;
@@ -275,7 +276,7 @@ static void free_factors(spike_handle h)
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
-    F(h->dTips); F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
+    F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
     h->gm_restart = 0;
     h->ready = false;
     h->chains.clear();
@@ -329,6 +330,12 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "subsplit") h->subsplit = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
+    else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
+        if (v == "refine_never" || v == "never") h->cgs_refine = 0;
+        else if (v == "refine_ifneeded" || v == "ifneeded") h->cgs_refine = 1;
+        else if (v == "refine_always" || v == "always") h->cgs_refine = 2;
+        else return fail(h, SPIKE_ERR_ARG, "unknown gmres_cgs_refinement_type '%s'", val);
+    }
     else return fail(h, SPIKE_ERR_ARG, "unknown option '%s'", key);
     return SPIKE_OK;
 }
@@ -380,7 +387,7 @@ extern "C" int spike_comm_init_local(spike_handle h, int nranks, int rank, int g
     return SPIKE_OK;
 }
 
-static int matvec_dev(spike_handle h, const double *x, double *y);
+static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace = nullptr, double scale = 1.0);
 
 // ---- partitioning ------------------------------------------------------------------------------------
 static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
@@ -478,21 +485,6 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     return SPIKE_OK;
 }
 
-__global__ void k_gather_tips(const double *g, int K, const ChainDesc *chains, int nchains, double *tips, double *send)
-{
-    const int p = blockIdx.x;
-    const ChainDesc cd = chains[p];
-    for (int a = threadIdx.x; a < K; a += blockDim.x) {
-        const double gt = g[cd.row0 + a], gb = g[cd.row0 + cd.nrows - K + a];
-        tips[((int64_t)p * 2) * K + a] = gt;
-        tips[((int64_t)p * 2 + 1) * K + a] = gb;
-        if (send) {
-            if (p == 0) send[a] = gt;
-            if (p == nchains - 1) send[K + a] = gb;
-        }
-    }
-}
-
 // band slots whose column falls outside [0, n_global) are "ignored" by the ABI: zero them in the library's copy so
 // that kernels may multiply them by (zero) halo values without masking
 __global__ void k_zero_corners(double *band, int64_t ld, int K, int64_t n_global, int64_t row0, int64_t n)
@@ -518,10 +510,17 @@ __global__ void k_copy_halo(const double *x, int64_t n, int K, double *send)
     }
 }
 
-__global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv, int rank, int nranks, double *xh)
+// xh = [left halo | x | right halo]; xs != nullptr: x is first scaled by s IN PLACE (xs aliases x: the normalisation of
+// the newest Krylov vector rides on the copy the mat-vec needs anyway)
+__global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv, int rank, int nranks, double *xh,
+                           double *xs, double s)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) xh[K + i] = x[i];
+    if (i < n) {
+        double v = x[i];
+        if (xs != nullptr) { v *= s; xs[i] = v; }
+        xh[K + i] = v;
+    }
     if (i < K) {
         xh[i] = (rank > 0) ? recv[((int64_t)(rank - 1) * 2 + 1) * K + i] : 0.0;
         xh[K + n + i] = (rank < nranks - 1) ? recv[((int64_t)(rank + 1) * 2) * K + i] : 0.0;
@@ -628,7 +627,6 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(dalloc(&h->dCorrBot, (size_t)P * K));
         HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
         HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
-        HIPCHK(dalloc(&h->dTips, (size_t)P * 2 * K));
     }
     if (nif > 0) {
         HIPCHK(dalloc(&h->dWt, (size_t)P * kk));
@@ -810,8 +808,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         std::vector<IfaceDesc> ifs(nif);
         for (int i = 0; i < nif_local; ++i) {
             IfaceDesc &d = ifs[i];
-            d.gb = h->dTips + ((size_t)i * 2 + 1) * K;
-            d.gt = h->dTips + ((size_t)(i + 1) * 2) * K;
+            d.gb = nullptr; d.gb_off = h->chains[i].row0 + h->chains[i].nrows - K;  // read in place from the swept vector
+            d.gt = nullptr; d.gt_off = h->chains[i + 1].row0;
             d.WT = h->dWT + (size_t)i * kk; d.ST = h->dST + (size_t)i * kk; d.VT = h->dVT + (size_t)i * kk;
             d.BT = h->dBT + (size_t)i * kk; d.CT = h->dCT + (size_t)(i + 1) * kk;
             d.corr_bot = h->dCorrBot + (size_t)i * K;
@@ -820,14 +818,14 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         if (ib_prev >= 0) {
             IfaceDesc &d = ifs[ib_prev];
             d.gb = h->dRecv + ((size_t)(h->rank - 1) * 2 + 1) * K;  // previous rank's gb_last (apply-time layout: 2K per rank)
-            d.gt = h->dTips;
+            d.gt = nullptr; d.gt_off = h->chains[0].row0; d.gb_off = 0;
             d.WT = h->dWT + (size_t)ib_prev * kk; d.ST = h->dST + (size_t)ib_prev * kk; d.VT = h->dVT + (size_t)ib_prev * kk;
             d.BT = nullptr; d.CT = h->dCT;
             d.corr_bot = nullptr; d.corr_top = h->dCorrTop;
         }
         if (ib_next >= 0) {
             IfaceDesc &d = ifs[ib_next];
-            d.gb = h->dTips + ((size_t)(P - 1) * 2 + 1) * K;
+            d.gb = nullptr; d.gb_off = h->chains[P - 1].row0 + h->chains[P - 1].nrows - K; d.gt_off = 0;
             d.gt = h->dRecv + ((size_t)(h->rank + 1) * 2) * K;  // next rank's gt_first
             d.WT = h->dWT + (size_t)ib_next * kk; d.ST = h->dST + (size_t)ib_next * kk; d.VT = h->dVT + (size_t)ib_next * kk;
             d.BT = h->dBT + (size_t)(P - 1) * kk; d.CT = nullptr;
@@ -903,23 +901,25 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     if (nif > 0) {
         const bool multi = coupled && exchanging(h);
         const int K = h->K, P = h->P;
-        hipLaunchKernelGGL(k_gather_tips, dim3(P), dim3(64), 0, st, y, K, h->dChains, P, h->dTips, multi ? h->dSend : nullptr);
-        HIPCHK(hipGetLastError());
-        if (multi && (rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K))) return rc;
+        if (multi) {  // [g_top(first partition) | g_bottom(last partition)] = the first and last K entries of the local vector
+            hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, y, h->n, K, h->dSend);
+            HIPCHK(hipGetLastError());
+            if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K))) return rc;
+        }
         if (h->spike_m > 0) {
             // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
             if (!coupled) {  // tip solutions of the caller-level interfaces must read as zero
                 HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
                 HIPCHK(hipMemsetAsync(h->dXt, 0, sizeof(double) * (P + 2) * K, st));
             }
-            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfsFast : h->dIfsFastInt, st));
+            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfsFast : h->dIfsFastInt, y, st));
             HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st));
         } else {
             if (!coupled) {
                 HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
                 HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
             }
-            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfs : h->dIfsInt, st));
+            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfs : h->dIfsInt, y, st));
             rc = run_pass(h, x, y, true);
             if (rc) return rc;
         }
@@ -960,10 +960,11 @@ extern "C" int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunc
 }
 
 // ---- matvec with the kept band ---------------------------------------------------------------------------
-static int matvec_dev(spike_handle h, const double *x, double *y)
+static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace, double scale)
 {
     hipStream_t st = h->stream;
     if (h->op_n > 0) {
+        if (scale_inplace) HIPCHK(launch_scale_value(scale_inplace, scale, h->op_n, st));
         HIPCHK(launch_csr_matvec(h->op_n, h->op_ia, h->op_ja, h->op_a, h->op_tpr, x, y, st));
         return SPIKE_OK;
     }
@@ -971,10 +972,11 @@ static int matvec_dev(spike_handle h, const double *x, double *y)
     if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
     const bool multi = exchanging(h);
     if (multi && K > 0) {
+        if (scale_inplace) { HIPCHK(launch_scale_value(scale_inplace, scale, h->n, st)); scale_inplace = nullptr; }  // the halo must be scaled too
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, x, h->n, K, h->dSend);
         { int rc2 = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K); if (rc2) return rc2; }
     }
-    hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh);
+    hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh, scale_inplace, scale);
     HIPCHK(hipGetLastError());
     if (h->dAtOp && !h->use_kept_band) {
         HIPCHK(launch_band_matvec_tiled(h->n, K, h->dAtOp, h->dXh, y, st));
@@ -1050,17 +1052,26 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
     hipStream_t st = h->stream;
     const int64_t n = h->op_n > 0 ? h->op_n : h->n;
     const int m = restart;
-    if (h->gm_restart != m) {
+    // Basis vectors n doubles apart would, for n a power of two, start on the same HBM channel and bank: a multi-vector
+    // pass then streams its j+2 vectors through ONE channel at a time.  The leading dimension is padded off the
+    // power-of-two grid (SPIKE_GMRES_PAD overrides, in doubles; measurement hook).
+    int64_t pad = 544;
+    if (const char *e = getenv("SPIKE_GMRES_PAD")) pad = atoll(e);
+    const int64_t ldv = n + pad;
+    if (h->gm_restart != m || h->gm_ldv != ldv) {
         auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-        F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef);
-        HIPCHK(dalloc(&h->dV, (size_t)(m + 1) * n));
+        F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
+        HIPCHK(dalloc(&h->dRedWs, red_workspace_doubles()));
+        HIPCHK(hipMemsetAsync(h->dRedWs, 0, sizeof(double) * red_workspace_doubles(), st));
+        HIPCHK(dalloc(&h->dV, (size_t)(m + 1) * ldv));
         HIPCHK(dalloc(&h->dW, (size_t)n));
         HIPCHK(dalloc(&h->dZ, (size_t)n));
-        HIPCHK(dalloc(&h->dDots, (size_t)m + 2));
+        HIPCHK(dalloc(&h->dDots, (size_t)m + 3));
         HIPCHK(dalloc(&h->dCoef, (size_t)m + 2));
         h->gm_restart = m;
+        h->gm_ldv = ldv;
     }
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m + 2), hcol(m + 2);
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), yv(m + 3), hcol(m + 2);
     int it = 0, rc = 0;
     bool conv = false;
     double r0 = -1.0, rn = 0.0;
@@ -1075,7 +1086,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
         if ((rc = matvec_dev(h, x, h->dW))) return rc;
         HIPCHK(launch_residual(b, h->dW, h->dW, n, st));
         if ((rc = precond(h->dW, h->dZ))) return rc;
-        HIPCHK(launch_dots(h->dZ, n, 1, h->dZ, n, h->dDots, st));
+        HIPCHK(launch_dots(h->dZ, n, 1, h->dZ, n, h->dDots, h->dRedWs, st));
         if ((rc = dist_sum(h, h->dDots, 1))) return rc;
         double bb = 0.0;
         HIPCHK(hipMemcpyAsync(&bb, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1088,38 +1099,34 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
         std::fill(g.begin(), g.end(), 0.0);
         g[0] = beta;
         int j = 0;
+        double pending_scale = 0.0;  // 1/h_{j+1,j} of the newest basis vector: applied by the next mat-vec's copy
         for (j = 0; j < m && it < maxit; ++j) {
-            double *vj = h->dV + (size_t)j * n, *vn = h->dV + (size_t)(j + 1) * n;
-            if ((rc = matvec_dev(h, vj, h->dW))) return rc;
+            double *vj = h->dV + (size_t)j * ldv, *vn = h->dV + (size_t)(j + 1) * ldv;
+            if ((rc = matvec_dev(h, vj, h->dW, pending_scale != 0.0 ? vj : nullptr, pending_scale))) return rc;
+            pending_scale = 0.0;
             if ((rc = precond(h->dW, vn))) return rc;
-            // classical Gram-Schmidt; ONE fused multi-dot pass also returns |vn|^2, so the norm of the orthogonalised
-            // vector comes from Pythagoras without a second reduction.  A second pass (and an explicit norm) is made
-            // only when cancellation is severe (DGKS criterion), like PETSc's -ksp_gmres_cgs_refinement_type ifneeded.
+            // Classical Gram-Schmidt as PETSc's default for -ksp_type gmres (the reference's options, src/makefile:18):
+            // one fused multi-dot pass (VecMDot: the new vector is read once for the whole column), one fused update
+            // (VecMAXPY) that also returns the norm of the result (VecNorm) -- two passes over the basis and ONE host
+            // synchronisation per iteration.  "gmres_cgs_refinement_type" = refine_never (PETSc's default) |
+            // refine_ifneeded (second pass when the norm dropped below 1/sqrt(2), PETSc's criterion) | refine_always.
             for (int i = 0; i <= j; ++i) hcol[i] = 0.0;
             double hn = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
-                // vn is stored right behind V_j, so "j+2 vectors" = V_0..V_j and vn itself
-                HIPCHK(launch_dots(h->dV, n, j + 2, vn, n, h->dDots, st));
+                // vn is stored right behind V_j, so "j+2 vectors" = V_0..V_j and vn itself (|vn|^2 before the update)
+                HIPCHK(launch_dots(h->dV, ldv, j + 2, vn, n, h->dDots, h->dRedWs, st));
                 if ((rc = dist_sum(h, h->dDots, j + 2))) return rc;
-                HIPCHK(launch_axpys(h->dV, n, j + 1, h->dDots, vn, n, -1.0, st));
-                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 2), hipMemcpyDeviceToHost, st));
+                HIPCHK(launch_axpys_norm(h->dV, ldv, j + 1, h->dDots, vn, n, -1.0, h->dDots + j + 2, h->dRedWs, st));
+                if ((rc = dist_sum(h, h->dDots + j + 2, 1))) return rc;
+                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 3), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                double s2 = 0.0;
-                for (int i = 0; i <= j; ++i) { hcol[i] += yv[i]; s2 += yv[i] * yv[i]; }
-                const double before = yv[j + 1], after = before - s2;
-                if (after > 0.5 * before || pass == 1) {
-                    if (after > 0.25 * before) { hn = std::sqrt(after); break; }
-                    // heavy cancellation even after refinement: take the norm explicitly
-                    HIPCHK(launch_dots(vn, n, 1, vn, n, h->dDots, st));
-                    if ((rc = dist_sum(h, h->dDots, 1))) return rc;
-                    double hh = 0.0;
-                    HIPCHK(hipMemcpyAsync(&hh, h->dDots, sizeof(double), hipMemcpyDeviceToHost, st));
-                    HIPCHK(hipStreamSynchronize(st));
-                    hn = std::sqrt(hh);
-                    break;
-                }
+                for (int i = 0; i <= j; ++i) hcol[i] += yv[i];
+                const double before = yv[j + 1], after = yv[j + 2];
+                hn = std::sqrt(after);
+                const bool again = pass == 0 && (h->cgs_refine == 2 || (h->cgs_refine == 1 && !(after > 0.5 * before)));
+                if (!again) break;
             }
-            if (hn != 0.0) HIPCHK(launch_scale_value(vn, 1.0 / hn, n, st));
+            if (hn != 0.0) pending_scale = 1.0 / hn;
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
             H[(size_t)(j + 1) * m + j] = hn;
             for (int i = 0; i < j; ++i) {
@@ -1146,7 +1153,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
             yv[i] = t / H[(size_t)i * m + i];
         }
         HIPCHK(hipMemcpyAsync(h->dCoef, yv.data(), sizeof(double) * jj, hipMemcpyHostToDevice, st));
-        HIPCHK(launch_lincomb(h->dV, n, jj, h->dCoef, x, n, st));
+        HIPCHK(launch_lincomb(h->dV, ldv, jj, h->dCoef, x, n, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipStreamSynchronize(st));

@@ -48,8 +48,10 @@ struct SweepArgs {
 
 // One reduced (interface) system between partition "lo" and the partition below it.
 struct IfaceDesc {
-    const double *gb;  // K doubles: bottom tip of g of the upper partition
-    const double *gt;  // K doubles: top tip of g of the lower partition
+    const double *gb;  // K doubles: bottom tip of g of the upper partition (a neighbour rank's, from the exchange buffer),
+    const double *gt;  // K doubles: top tip of g of the lower partition     or null: read g + gb_off / g + gt_off
+    int64_t gb_off;    // local partitions: the tips are read in place from the swept vector g (no gather kernel)
+    int64_t gt_off;
     const double *WT;  // K*K, column-major W^(t)   (WT[c*K+a] = W[a][c])
     const double *ST;  // K*K, column-major (I - W V)^{-1}
     const double *VT;  // K*K, column-major V^(b)
@@ -94,7 +96,7 @@ hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t
 // outputs column-major WT, VT, ST.  flag[i] != 0 when interface i is singular.
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st);
-hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st);
+hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st);
 // stored (decayed) spikes: gather m rows of a spike column, measure what lies outside the window, and the
 // second "pass" of the coupled variant as a dense correction  x -= W x_b(prev) (top m rows), x -= V x_t(next)
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
@@ -111,10 +113,15 @@ hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, co
                              double *y, hipStream_t st);
 hipError_t launch_csr_to_band(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int K, double *band,
                               int64_t ld, hipStream_t st);
+// deterministic grid reductions: ws = red_workspace_doubles() doubles of per-workgroup partials
+size_t red_workspace_doubles();
 hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out /*nvec*/,
-                       hipStream_t st);
+                       double *ws, hipStream_t st);
 hipError_t launch_axpys(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,
                         hipStream_t st);
+// w += sign * sum coef_i V_i and norm2_out[0] = |w|^2 of the result, in the same pass
+hipError_t launch_axpys_norm(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,
+                             double *norm2_out, double *ws, hipStream_t st);
 hipError_t launch_scale_copy(const double *w, const double *scal_dev, int invert, double *out, int64_t n,
                              hipStream_t st);
 hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st);

@@ -1107,7 +1107,7 @@ __device__ __forceinline__ double iface_matvec(const double *MT, const double *x
     return s;
 }
 
-__global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs)
+__global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs, const double *g)
 {
     extern __shared__ double sh[];
     double *gb = sh, *gt = sh + K, *v1 = sh + 2 * K, *v2 = sh + 3 * K;
@@ -1118,7 +1118,8 @@ __global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs
     while (KA < K) KA <<= 1;
     const int nparts = (int)blockDim.x / KA;
     const int a = tid % KA, part = tid / KA;
-    for (int t = tid; t < K; t += (int)blockDim.x) { gb[t] = d.gb[t]; gt[t] = d.gt[t]; }
+    const double *pgb = d.gb != nullptr ? d.gb : g + d.gb_off, *pgt = d.gt != nullptr ? d.gt : g + d.gt_off;
+    for (int t = tid; t < K; t += (int)blockDim.x) { gb[t] = pgb[t]; gt[t] = pgt[t]; }
     __syncthreads();
     // t = gt - W gb
     double s = iface_matvec(d.WT, gb, K, KA, nparts, a, part, redb);
@@ -1146,12 +1147,12 @@ __global__ __launch_bounds__(IFT) void k_iface_apply(int K, const IfaceDesc *ifs
     }
 }
 
-hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, hipStream_t st)
+hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st)
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
     int nt = 64;
     while (nt < IFT && nt < 8 * K) nt <<= 1;  // K = 128 -> 1024 threads, K <= 8 -> one wave
-    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs);
+    hipLaunchKernelGGL(k_iface_apply, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs, g);
     return hipGetLastError();
 }
 

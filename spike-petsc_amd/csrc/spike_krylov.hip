@@ -9,20 +9,21 @@
 
 namespace spike {
 
-// out[v0+i] += V_{v0+i} . w   for i < NV (masked by nvec); one atomic per wave per vector
+// ---- deterministic grid reductions ---------------------------------------------------------------------------------
+// Every workgroup writes its NV partial sums to part[block][NV]; a one-workgroup kernel then adds the partials of all
+// workgroups in a fixed order and writes out[].  No floating-point atomics: a dot product has the same bits in every
+// run (the Krylov iteration is reproducible), and one launch pair serves the whole Gram-Schmidt column.  The kernel
+// boundary is the only synchronisation: a "last workgroup finishes" ticket needs device-scope fences, which on this
+// chip write back / invalidate the XCD's L2 once per workgroup (measured: 2-3x slower kernels).
+constexpr int RED_BLOCKS = 2048;  // grid of the reduction kernels (8 workgroups = 32 waves per CU: every wave resident)
+constexpr int RED_MAXV = 32;      // vectors per launch
+
+// rows per workgroup when `grid` workgroups of 256 threads split n rows into contiguous runs (a multiple of 256)
+__host__ __device__ inline int64_t block_chunk(int64_t n, int64_t grid) { return (((n + grid - 1) / grid) + 255) & ~(int64_t)255; }
+
 template <int NV>
-__global__ __launch_bounds__(256) void k_dots(const double *V, int64_t ldv, int v0, int nvec, const double *w, int64_t n,
-                                              double *out)
+__device__ __forceinline__ void block_partials(double (&acc)[NV], double *part)
 {
-    double acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-        const double wv = w[r];
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (v0 + i < nvec) acc[i] = fma(V[(int64_t)(v0 + i) * ldv + r], wv, acc[i]);
-    }
     __shared__ double red[4][NV];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -32,36 +33,134 @@ __global__ __launch_bounds__(256) void k_dots(const double *V, int64_t ldv, int 
         if (lane == 0) red[wv][i] = a;
     }
     __syncthreads();
-    if (threadIdx.x < NV && v0 + (int)threadIdx.x < nvec) {
-        const double s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + v0 + threadIdx.x, s);
-    }
+    if (threadIdx.x < NV)
+        part[(int64_t)blockIdx.x * NV + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out, hipStream_t st)
+// all NV sums at once: thread t owns vector t % NV and every (1024/NV)-th workgroup's partial (coalesced reads, fixed
+// order), then a fixed tree over the 1024/NV chunks
+template <int NV>
+__global__ __launch_bounds__(1024) void k_reduce_final(const double *part, int nblocks, int nout, double *out)
 {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * nvec, st);
-    if (e != hipSuccess) return e;
-    int grid = (int)((n + 1023) / 1024);
-    if (grid > 1024) grid = 1024;
-    if (grid < 1) grid = 1;
-    for (int v0 = 0; v0 < nvec; v0 += 8)
-        hipLaunchKernelGGL((k_dots<8>), dim3(grid), dim3(256), 0, st, V, ldv, v0, nvec, w, n, out);
+    __shared__ double fin[1024];
+    constexpr int NCH = 1024 / NV;
+    const int i = threadIdx.x % NV, c = threadIdx.x / NV;
+    double a = 0.0;
+    for (int b = c; b < nblocks; b += NCH) a += part[(int64_t)b * NV + i];
+    fin[threadIdx.x] = a;
+    __syncthreads();
+#pragma unroll
+    for (int o = NCH / 2; o > 0; o >>= 1) {
+        if (c < o) fin[threadIdx.x] += fin[threadIdx.x + o * NV];
+        __syncthreads();
+    }
+    if (c == 0 && i < nout) out[i] = fin[i];
+}
+
+// out[i] = V_i . w   for i < nvec <= NV; w is read once for all vectors
+template <int NV>
+__global__ __launch_bounds__(256) void k_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n,
+                                              double *part)
+{
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    // a workgroup owns ONE contiguous run of rows of every vector (not a grid-stride comb): consecutive trips touch
+    // adjacent 2-KiB segments, so a CU works inside a few pages per vector instead of a new page per vector per trip
+    constexpr int U = NV <= 8 ? 4 : (NV <= 16 ? 2 : 1);  // rows per lane and trip: keeps >= 32 loads in flight per lane
+    const int64_t chunk = block_chunk(n, gridDim.x);
+    const int64_t end = (blockIdx.x + 1) * chunk < n ? (blockIdx.x + 1) * chunk : n;
+    // every load is unconditional (out-of-range rows / vectors are clamped to a valid address and weighted by zero, or
+    // land in accumulators nobody reads): loads under a branch are not batched by the compiler, and a lane that waits for
+    // each one separately leaves the memory system idle
+    for (int64_t r0 = blockIdx.x * chunk + threadIdx.x; r0 < end; r0 += U * 256) {
+        double wv[U];
+        int64_t rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = r0 + u * 256 < end;
+            rr[u] = in ? r0 + u * 256 : r0;
+            wv[u] = w[rr[u]];
+            if (!in) wv[u] = 0.0;
+        }
+        double xv[NV][U];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int64_t base = (int64_t)(i < nvec ? i : 0) * ldv;
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[i][u] = V[base + rr[u]];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[i] = fma(xv[i][u], wv[u], acc[i]);
+    }
+    block_partials<NV>(acc, part);
+}
+
+static int red_grid(int64_t n)
+{
+    int grid = (int)((n + 511) / 512);
+    return grid > RED_BLOCKS ? RED_BLOCKS : (grid < 1 ? 1 : grid);
+}
+
+// ws: RED_BLOCKS*RED_MAXV doubles of partials
+size_t red_workspace_doubles() { return (size_t)RED_BLOCKS * RED_MAXV; }
+
+template <int NV>
+static void launch_dots_t(const double *V, int64_t ldv, int nv, const double *w, int64_t n, double *out, double *ws,
+                          hipStream_t st)
+{
+    const int grid = red_grid(n);
+    hipLaunchKernelGGL((k_dots<NV>), dim3(grid), dim3(256), 0, st, V, ldv, nv, w, n, ws);
+    hipLaunchKernelGGL((k_reduce_final<NV>), dim3(1), dim3(1024), 0, st, ws, grid, nv, out);
+}
+
+hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out, double *ws,
+                       hipStream_t st)
+{
+    for (int v0 = 0; v0 < nvec; v0 += RED_MAXV) {
+        const int nv = nvec - v0 < RED_MAXV ? nvec - v0 : RED_MAXV;
+        const double *Vp = V + (int64_t)v0 * ldv;
+        if (nv <= 4) launch_dots_t<4>(Vp, ldv, nv, w, n, out + v0, ws, st);
+        else if (nv <= 8) launch_dots_t<8>(Vp, ldv, nv, w, n, out + v0, ws, st);
+        else if (nv <= 16) launch_dots_t<16>(Vp, ldv, nv, w, n, out + v0, ws, st);
+        else launch_dots_t<32>(Vp, ldv, nv, w, n, out + v0, ws, st);
+    }
     return hipGetLastError();
 }
 
-// w += sign * sum_i coef[i] V_i
+// w += sign * sum_i coef[i] V_i ; NORM: also norm2_out[0] = |w_new|^2 (deterministic grid reduction), so the norm of
+// the orthogonalised Krylov vector costs no extra pass over it (PETSc: VecMAXPY followed by VecNorm)
+template <bool NORM>
 __global__ __launch_bounds__(256) void k_axpys(const double *V, int64_t ldv, int nvec, const double *coef, double *w,
-                                               int64_t n, double sign)
+                                               int64_t n, double sign, double *part)
 {
     __shared__ double cf[64];
     for (int i = threadIdx.x; i < nvec && i < 64; i += blockDim.x) cf[i] = coef[i];
     __syncthreads();
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int i = 0; i < nvec; ++i) s = fma(cf[i], V[(int64_t)i * ldv + r], s);
-        w[r] += sign * s;
+    double acc[1] = {0.0};
+    const int64_t chunk = block_chunk(n, gridDim.x);
+    const int64_t end = (blockIdx.x + 1) * chunk < n ? (blockIdx.x + 1) * chunk : n;
+    for (int64_t r = blockIdx.x * chunk + threadIdx.x; r < end; r += 512) {
+        const bool two = r + 256 < end;
+        const int64_t r1 = two ? r + 256 : r;   // clamped: the loads below stay unconditional
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < nvec; ++i) {
+            s0 = fma(cf[i], V[(int64_t)i * ldv + r], s0);
+            s1 = fma(cf[i], V[(int64_t)i * ldv + r1], s1);
+        }
+        const double v0 = w[r] + sign * s0;
+        const double v1 = w[r1] + sign * s1;
+        w[r] = v0;
+        if (NORM) acc[0] = fma(v0, v0, acc[0]);
+        if (two) {
+            w[r1] = v1;
+            if (NORM) acc[0] = fma(v1, v1, acc[0]);
+        }
     }
+    if (NORM) block_partials<1>(acc, part);
 }
 
 hipError_t launch_axpys(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,
@@ -69,9 +168,18 @@ hipError_t launch_axpys(const double *V, int64_t ldv, int nvec, const double *co
 {
     if (nvec <= 0) return hipSuccess;
     if (nvec > 64) return hipErrorInvalidValue;
-    int grid = (int)((n + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_axpys, dim3(grid), dim3(256), 0, st, V, ldv, nvec, coef, w, n, sign);
+    const int grid = red_grid(n);
+    hipLaunchKernelGGL((k_axpys<false>), dim3(grid), dim3(256), 0, st, V, ldv, nvec, coef, w, n, sign, (double *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_axpys_norm(const double *V, int64_t ldv, int nvec, const double *coef, double *w, int64_t n, double sign,
+                             double *norm2_out, double *ws, hipStream_t st)
+{
+    if (nvec <= 0 || nvec > 64) return hipErrorInvalidValue;
+    const int grid = red_grid(n);
+    hipLaunchKernelGGL((k_axpys<true>), dim3(grid), dim3(256), 0, st, V, ldv, nvec, coef, w, n, sign, ws);
+    hipLaunchKernelGGL((k_reduce_final<1>), dim3(1), dim3(1024), 0, st, ws, grid, 1, norm2_out);
     return hipGetLastError();
 }
 

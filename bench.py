@@ -49,7 +49,7 @@ def pmc_traffic(N, K, world):
     return None
 
 
-def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
+def cpu_baseline(K, rows_per_part, variant, budget_rows=None, max_parts=64):
     """The oracle (CPU port of the same algorithm) timed on this host, on a bounded sample."""
     import numpy as np
     import oracle as O
@@ -57,8 +57,12 @@ def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
         L = O.lib(O.build(native=True))
     except Exception:
         L = O.lib()
-    N = budget_rows
-    P = max(1, N // rows_per_part)
+    # the oracle is parallel over partitions: give every host thread one (up to max_parts), same rows/partition as the GPU
+    nthreads = int(L.orc_num_threads())
+    P = max(1, min(nthreads, max_parts)) if budget_rows is None else max(1, budget_rows // rows_per_part)
+    while P > 1 and P * rows_per_part * (2 * K + 1) * 8 > 3 * 2 ** 30:   # bounded sample: at most 3 GiB of band
+        P //= 2
+    N = P * rows_per_part
     band = O.gen_band(N, K, L=L)
     f = O.gen_vec(N)
     t0 = time.perf_counter()
@@ -73,11 +77,24 @@ def cpu_baseline(K, rows_per_part, variant, budget_rows=131072):
         t = time.perf_counter() - t0
     per = t / reps
     p = 2 if variant == 1 else 1
+    # one thread = what a single PETSc rank of the reference does; bounded to a few applies
+    one = None
+    try:
+        L.orc_set_num_threads(1)
+        t0 = time.perf_counter()
+        r1 = 0
+        while r1 < 1 or (time.perf_counter() - t0 < 4.0 and r1 < 5):
+            sp.apply(f, variant)
+            r1 += 1
+        one = alg_bytes(N, K, p, P, variant == 1) / ((time.perf_counter() - t0) / r1) / 1e9
+    finally:
+        L.orc_set_num_threads(nthreads)
     return {
-        "value": alg_bytes(N, K, p, P, variant == 1) / per / 1e9, "unit": "GB/s", "cores": int(L.orc_num_threads()), "kind": "port",
+        "value": alg_bytes(N, K, p, P, variant == 1) / per / 1e9, "unit": "GB/s", "cores": min(nthreads, P), "kind": "port",
+        "value_one_thread": one,
         "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition as on the GPU), "
-                  "%s variant, %d applies, setup %.1f s not timed" % (N, K, P, rows_per_part,
-                                                                     "coupled" if variant else "decoupled", reps, t_setup),
+                  "%s variant (two passes over the factors), %d applies on %d of %d host threads, setup %.1f s not timed"
+                  % (N, K, P, rows_per_part, "coupled" if variant else "decoupled", reps, min(nthreads, P), nthreads, t_setup),
     }
 
 

@@ -91,7 +91,9 @@ const char *spike_last_error(spike_handle h);
  *       "subsplit" ("auto"|"off": a caller-chosen partition count is honoured, but each partition may be swept as
  *        several chains when setup MEASURES that the spikes die inside a chain, which leaves the preconditioner
  *        unchanged to rounding; off: exactly one chain per partition),
- *       "profile" (0|1: record HIP events around the sweep launches)                                  */
+ *       "profile" (0|1: record HIP events around the sweep launches),
+ *       "gmres_cgs_refinement_type" ("refine_never"|"refine_ifneeded"|"refine_always": the Gram-Schmidt refinement of
+ *        spike_gmres, names and default (never) of PETSc's -ksp_gmres_cgs_refinement_type)             */
 int spike_set_option(spike_handle h, const char *key, const char *value);
 /* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */
 int spike_set_stream(spike_handle h, void *hip_stream);

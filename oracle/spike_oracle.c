@@ -499,3 +499,13 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* bench.py's cpu_baseline reports an all-cores figure and a one-thread figure (what one PETSc rank would do) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

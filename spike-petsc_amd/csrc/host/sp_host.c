@@ -754,6 +754,11 @@ static PetscErrorCode KSPSolve_GMRES(KSP ksp)
     if (spike_dev_malloc(&db, sizeof(double) * (size_t)n) || spike_dev_malloc(&dx, sizeof(double) * (size_t)n)) return seterr(PETSC_ERR_MEM, "device allocation");
     spike_dev_upload(db, ksp->vec_rhs->a, sizeof(double) * (size_t)n);
     spike_dev_upload(dx, ksp->vec_sol->a, sizeof(double) * (size_t)n);
+    {   /* PETSc's -ksp_gmres_cgs_refinement_type refine_never|refine_ifneeded|refine_always (default refine_never) */
+        char rt[32];
+        if (opt_str(ksp->prefix, "ksp_gmres_cgs_refinement_type", rt, sizeof rt) && spike_set_option(h, "gmres_cgs_refinement_type", rt))
+            return seterr(PETSC_ERR_ARG_OUTOFRANGE, "libspike_mi355: %s", spike_last_error(h));
+    }
     int its = 0;
     double rn = 0, ms = 0;
     const int rc = spike_gmres(h, (const double *)db, (double *)dx, (int)ksp->restart, ksp->rtol, (int)ksp->max_it, use_pc, &its, &rn, &ms);

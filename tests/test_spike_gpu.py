@@ -314,3 +314,35 @@ def test_gmres_on_a_nearby_banded_operator(spike, oracle, torch_cuda):
     assert abs(it - ito) <= 1
     sp.set_operator_band(None)
     assert _rel(sp.matvec(torch.from_numpy(u).cuda()).cpu().numpy(), oracle.band_matvec(A, u)) <= 1e-14
+
+
+def test_gmres_refinement_types_and_bitwise_reproducibility(spike, oracle, torch_cuda):
+    """PETSc's -ksp_gmres_cgs_refinement_type names; the Krylov reductions are fixed-order (no floating-point atomics),
+    so the same solve gives the same BITS twice -- with and without the preconditioner, n not a multiple of anything"""
+    torch = torch_cuda
+    N, K, P = 40000 + 37, 24, 8
+    A = oracle.gen_band(N, K, delta=1.2)
+    A2 = oracle.gen_band(N, K, delta=0.9)
+    u = oracle.gen_vec(N, seed=5)
+    sp = spike.Spike(partitions=P).setup_band(A)
+    sp.set_operator_band(torch.from_numpy(A2).cuda())
+    b = sp.operator_matvec(torch.from_numpy(u).cuda())
+    sols = {}
+    for rt in ("refine_never", "refine_ifneeded", "refine_always"):
+        sp.set_option("gmres_cgs_refinement_type", rt)
+        x = torch.zeros(N, dtype=torch.float64, device="cuda")
+        it, rn, ms, ok = sp.gmres(b, x, restart=30, rtol=1e-11, maxit=300)
+        assert ok and it >= 3
+        assert _rel(x.cpu().numpy(), u) <= 1e-8
+        x2 = torch.zeros(N, dtype=torch.float64, device="cuda")
+        it2, rn2, _, ok2 = sp.gmres(b, x2, restart=30, rtol=1e-11, maxit=300)
+        assert it2 == it and rn2 == rn and torch.equal(x, x2)            # bit for bit
+        sols[rt] = (it, x.cpu().numpy())
+    assert abs(sols["refine_never"][0] - sols["refine_always"][0]) <= 1
+    with pytest.raises(Exception):
+        sp.set_option("gmres_cgs_refinement_type", "sometimes")
+    # unpreconditioned, restart shorter than the iteration count (restarts exercise the pending normalisation)
+    sp.set_option("gmres_cgs_refinement_type", "refine_never")
+    x = torch.zeros(N, dtype=torch.float64, device="cuda")
+    it, rn, ms, ok = sp.gmres(b, x, restart=5, rtol=1e-9, maxit=400, use_pc=False)
+    assert ok and it > 5 and _rel(x.cpu().numpy(), u) <= 1e-6

@@ -732,16 +732,39 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 subBot.chains = dSubC[1]; subBot.groupsF = dSubG[2]; subBot.groupsB = dSubG[3];
             }
         }
+        // The 2K spike columns are solved SWEEP_MULTI_NR at a time (k_sweep_multi: a factor tile is read once for the
+        // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
+        const bool batched = cfg.R == 64 && !cfg.scan;
+        const int NRB = batched ? SWEEP_MULTI_NR : 1;
+        double *rhsM = rhs, *solM = sol, *midM = h->dY;
+        if (batched) {
+            HIPCHK(tmp.alloc(&rhsM, (size_t)NRB * n));
+            HIPCHK(tmp.alloc(&solM, (size_t)NRB * n));
+            HIPCHK(tmp.alloc(&midM, (size_t)NRB * n));
+        }
         for (int which = 0; which < 2; ++which) {
-            HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
-            for (int col = 0; col < K; ++col) {
-                HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
-                rc = run_pass(h, rhs, sol, false, partial ? (which == 0 ? &subTop : &subBot) : nullptr);
-                if (rc) return rc;
-                HIPCHK(launch_tip_gather(sol, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st));
-                if (m > 0) HIPCHK(launch_spike_gather(sol, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st));
+            HIPCHK(hipMemsetAsync(rhsM, 0, sizeof(double) * n * NRB, st));
+            const SubChains *sub = partial ? (which == 0 ? &subTop : &subBot) : nullptr;
+            for (int col = 0; col < K; col += NRB) {
+                const int nc = std::min(NRB, K - col);  // a short last batch solves stale columns too; they are not gathered
+                HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhsM, st, nc, n));
+                if (batched) {
+                    SweepArgs a;
+                    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = P; a.K = K;
+                    a.tiles = h->dLt; a.in = rhsM; a.out = midM; a.dinv = h->dDinv; a.corr_top = a.corr_bot = nullptr;
+                    HIPCHK(launch_sweep_multi(cfg, false, P, a, n, st));
+                    a.tiles = h->dUt; a.in = midM; a.out = solM; a.dinv = nullptr;
+                    if (sub) a.groups = sub->groupsB;
+                    HIPCHK(launch_sweep_multi(cfg, true, P, a, n, st));
+                } else {
+                    rc = run_pass(h, rhsM, solM, false, sub);
+                    if (rc) return rc;
+                }
+                HIPCHK(launch_tip_gather(solM, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st, nc, n));
+                if (m > 0) HIPCHK(launch_spike_gather(solM, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st, nc, n));
             }
         }
+        if (batched) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
         h->profile = keep_prof;
         if (m > 0) {
             double stat[2] = {0, 0};

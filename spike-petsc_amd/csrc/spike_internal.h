@@ -67,6 +67,11 @@ bool pick_cfg(int K, SweepCfg *cfg);
 
 // launchers (spike_kernels.hip)
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag = 0);
+// setup: SWEEP_MULTI_NR right-hand sides per launch (R = 64 configurations), vector q at in/out + q*ldr.
+// Measured at N = 4M, K = 128 (partial chains of 26 row blocks): 1 rhs 145 us, 2 rhs 137 us, 3 rhs 300 us, 4 rhs 380 us per
+// launch -- two vectors ride on one pass over the factors for free; beyond that the block step is no longer memory-bound.
+constexpr int SWEEP_MULTI_NR = 2;
+hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st);
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st);
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
@@ -86,9 +91,10 @@ hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const do
 // tips: rhs[row0+a] = block(a,b) for every chain (which: 0 = C at top rows of chains with has_top,
 // 1 = B at bottom rows of chains with has_bot); gather copies K rows of sol into column b of out.
 hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st);
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st,
+                          int ncols = 1, int64_t ldr = 0);
 hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, int nchains, int which, int col,
-                             double *out, hipStream_t st);
+                             double *out, hipStream_t st, int ncols = 1, int64_t ldr = 0);
 // coupling blocks B (which=1) / C (which=0) of every chain as dense column-major K x K
 hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
                                   const ChainDesc *chains, int nchains, int which, double *out, hipStream_t st);
@@ -100,7 +106,8 @@ hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double
 // stored (decayed) spikes: gather m rows of a spike column, measure what lies outside the window, and the
 // second "pass" of the coupled variant as a dense correction  x -= W x_b(prev) (top m rows), x -= V x_t(next)
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
-                               double *out, double *absmax_in, double *absmax_out, hipStream_t st);
+                               double *out, double *absmax_in, double *absmax_out, hipStream_t st, int ncols = 1,
+                               int64_t ldr = 0);
 hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
                                int *extent, hipStream_t st);
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,

@@ -223,6 +223,153 @@ hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepA
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sweep_multi: the same sweep for NR right-hand sides at once (setup: the 2K spike columns).  A tile is loaded into
+// registers ONCE and used for NR vectors, so the spike solves read the factors 2K/NR times instead of 2K times; the
+// two workgroup barriers of a block step are shared by the NR vectors.  R = 64, DPW = 32 only (one chain per workgroup);
+// right-hand side q lives at in + q*ldr / out + q*ldr.  No corrections (setup never needs them).
+// ------------------------------------------------------------------------------------------
+template <int NW, bool REV, int NR>
+__global__ __launch_bounds__(NW * 64) void k_sweep_multi(SweepArgs a, int64_t ldr)
+{
+    constexpr int R = 64, DPW = 32;
+    constexpr int KP = DPW * NW;
+    constexpr int NLD = DPW / 2;
+    constexpr int WS = next_pow2(KP + R);
+    constexpr int NWB = 2 < NW ? 2 : NW;   // (R - 2) / DPW + 1 = 2 waves own in-block entries
+    constexpr int64_t TILE2 = (int64_t)NW * NLD * 64;
+
+    __shared__ double W[NR][2 * WS];
+    __shared__ double W2[NR][KP + R];
+    __shared__ double red[NR][NW][64];
+    __shared__ double red2[NR][NWB][64];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x;
+    if (p >= a.nchains) return;
+    const ChainDesc cd = a.chains[p];
+    const GroupDesc gd = a.groups[p];
+
+    for (int t = threadIdx.x; t < NR * 2 * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
+    for (int t = threadIdx.x; t < NR * (KP + R); t += NW * 64) (&W2[0][0])[t] = 0.0;
+    __syncthreads();
+
+    const d2 *tp = reinterpret_cast<const d2 *>(a.tiles) + gd.tile0 * TILE2 + (int64_t)(w * NLD) * 64 + lane;
+    d2 tA[NLD], tB[NLD];
+    int pos = 0;
+
+    auto load_tile = [&](d2(&t)[NLD], int s) {
+        const d2 *q = tp + (int64_t)s * TILE2;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) t[i] = __builtin_nontemporal_load(q + i * 64);
+    };
+
+    auto step = [&](const d2(&t)[NLD], int s) {
+        const int rl = REV ? (cd.nsteps * R - 1 - (s * R + lane)) : (s * R + lane);
+        const bool act = s < cd.nsteps && rl < cd.nrows;
+        const int64_t gi = cd.row0 + rl;
+        double fv[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) fv[q] = act ? a.in[q * ldr + gi] : 0.0;
+        double dv = 1.0;
+        if (!REV && act) dv = a.dinv[gi];
+        const int slot = (pos + lane) & (WS - 1);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { W[q][slot] = 0.0; W[q][slot + WS] = 0.0; }
+        WAVE_LDS_FENCE();
+        const int base = (pos & (WS - 1)) + WS + lane - KP - w * DPW;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const double *wp = &W[q][base];
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                acc0 = fma(t[i].x, wp[KP - 1 - 2 * i], acc0);
+                acc1 = fma(t[i].y, wp[KP - 2 - 2 * i], acc1);
+            }
+            red[q][w][lane] = acc0 + acc1;
+            __builtin_amdgcn_sched_barrier(0);  // one vector's window values in registers at a time (VGPR budget: 2 waves/SIMD)
+        }
+        __syncthreads();
+        double tt[NR], g[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            double acc = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) acc += red[q][ww][lane];
+            tt[q] = fv[q] - acc;
+            W2[q][KP + lane] = tt[q];
+        }
+        WAVE_LDS_FENCE();
+        if (w < NWB) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int d0 = w * DPW + 1 + 2 * i;
+                    b0 = fma(t[i].x, W2[q][KP + lane - d0], b0);
+                    b1 = fma(t[i].y, W2[q][KP + lane - d0 - 1], b1);
+                }
+                red2[q][w][lane] = b0 + b1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NWB; ++ww) s2 += red2[q][ww][lane];
+            g[q] = tt[q] - s2;
+        }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { W[q][slot] = g[q]; W[q][slot + WS] = g[q]; }
+        WAVE_LDS_FENCE();
+        if (act && w == 0) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) a.out[q * ldr + gi] = REV ? g[q] : g[q] * dv;
+        }
+        pos += R;
+    };
+
+    const int ns = gd.maxsteps;
+    if (ns > 0) load_tile(tA, 0);
+    for (int s = 0; s < ns; s += 2) {
+        if (s + 1 < ns) load_tile(tB, s + 1);
+        step(tA, s);
+        if (s + 1 < ns) {
+            if (s + 2 < ns) load_tile(tA, s + 2);
+            step(tB, s + 1);
+        }
+    }
+}
+
+template <int NW>
+static hipError_t launch_sweep_multi_t(bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st)
+{
+    if (rev) hipLaunchKernelGGL((k_sweep_multi<NW, true, SWEEP_MULTI_NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
+    else hipLaunchKernelGGL((k_sweep_multi<NW, false, SWEEP_MULTI_NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
+    return hipGetLastError();
+}
+
+// one chain per workgroup (groups[p] describes chain p): configurations with R = 64 only
+hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    if (cfg.R != 64 || cfg.scan) return hipErrorInvalidValue;
+    switch (cfg.NW) {
+    case 2: return launch_sweep_multi_t<2>(rev, nchains, a, ldr, st);
+    case 3: return launch_sweep_multi_t<3>(rev, nchains, a, ldr, st);
+    case 4: return launch_sweep_multi_t<4>(rev, nchains, a, ldr, st);
+    case 6: return launch_sweep_multi_t<6>(rev, nchains, a, ldr, st);
+    case 8: return launch_sweep_multi_t<8>(rev, nchains, a, ldr, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_scan_sweep: the narrow-band (K = 1) solve as a WAVEFRONT-LEVEL SCAN.  A first-order recurrence
 //   forward  g_i = f_i - l_i g_{i-1},   backward  x_i = y_i - c_i x_{i+1}
 // is the composition of affine maps  t -> a_i t + b_i; 64 consecutive rows sit on the 64 lanes of a wave, an inclusive
@@ -932,10 +1079,12 @@ __device__ __forceinline__ bool has_bot(const ChainDesc &cd, int64_t grow0, int6
 }
 
 __global__ void k_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs)
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, int64_t ldr)
 {
     const int p = blockIdx.x;
     const ChainDesc cd = chains[p];
+    col += blockIdx.y;            // column col0 + q goes to right-hand side q
+    rhs += blockIdx.y * ldr;
     for (int a = threadIdx.x; a < K; a += blockDim.x) {
         if (which == 0) {
             if (!has_top(cd, grow0)) continue;
@@ -950,18 +1099,21 @@ __global__ void k_tip_rhs(const double *band, int64_t ld, int K, int64_t n_globa
 }
 
 hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st)
+                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st, int ncols,
+                          int64_t ldr)
 {
-    if (nchains <= 0 || K <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tip_rhs, dim3(nchains), dim3(64), 0, st, band, ld, K, n_global, grow0, chains, nchains, which,
-                       col, rhs);
+    if (nchains <= 0 || K <= 0 || ncols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tip_rhs, dim3(nchains, ncols), dim3(64), 0, st, band, ld, K, n_global, grow0, chains, nchains, which,
+                       col, rhs, ldr);
     return hipGetLastError();
 }
 
-__global__ void k_tip_gather(const double *sol, int K, const ChainDesc *chains, int which, int col, double *out)
+__global__ void k_tip_gather(const double *sol, int K, const ChainDesc *chains, int which, int col, double *out, int64_t ldr)
 {
     const int p = blockIdx.x;
     const ChainDesc cd = chains[p];
+    col += blockIdx.y;
+    sol += blockIdx.y * ldr;
     for (int a = threadIdx.x; a < K; a += blockDim.x) {
         const int64_t r = (which == 0) ? cd.row0 + a : cd.row0 + cd.nrows - K + a;
         out[((int64_t)p * K + a) * K + col] = sol[r];
@@ -969,10 +1121,10 @@ __global__ void k_tip_gather(const double *sol, int K, const ChainDesc *chains, 
 }
 
 hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, int nchains, int which, int col,
-                             double *out, hipStream_t st)
+                             double *out, hipStream_t st, int ncols, int64_t ldr)
 {
-    if (nchains <= 0 || K <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tip_gather, dim3(nchains), dim3(64), 0, st, sol, K, chains, which, col, out);
+    if (nchains <= 0 || K <= 0 || ncols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tip_gather, dim3(nchains, ncols), dim3(64), 0, st, sol, K, chains, which, col, out, ldr);
     return hipGetLastError();
 }
 
@@ -1169,10 +1321,12 @@ __device__ __forceinline__ void atomic_max_pos(double *addr, double v)
 // which = 0: W (rows [0,m) of each chain); which = 1: V (rows [nrows-m, nrows)).  absmax_in = peak magnitude inside the
 // window, absmax_edge = peak over the 32 window rows farthest from the interface (must be ~0 for a decayed spike).
 __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int which,
-                                                      int col, double *out, double *absmax_in, double *absmax_edge)
+                                                      int col, double *out, double *absmax_in, double *absmax_edge, int64_t ldr)
 {
     const int p = blockIdx.y;
     const ChainDesc cd = chains[p];
+    col += blockIdx.z;
+    sol += blockIdx.z * ldr;
     double mi = 0.0, mo = 0.0;
     for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < m; w += gridDim.x * blockDim.x) {
         const int r = which == 0 ? w : cd.nrows - m + w;
@@ -1191,11 +1345,11 @@ __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, 
 }
 
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,
-                               double *out, double *absmax_in, double *absmax_out, hipStream_t st)
+                               double *out, double *absmax_in, double *absmax_out, hipStream_t st, int ncols, int64_t ldr)
 {
-    if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spike_gather, dim3((m + 255) / 256 < 8 ? (m + 255) / 256 : 8, nchains), dim3(256), 0, st, sol, K, m,
-                       chains, which, col, out, absmax_in, absmax_out);
+    if (nchains <= 0 || K <= 0 || m <= 0 || ncols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spike_gather, dim3((m + 255) / 256 < 8 ? (m + 255) / 256 : 8, nchains, ncols), dim3(256), 0, st, sol, K, m,
+                       chains, which, col, out, absmax_in, absmax_out, ldr);
     return hipGetLastError();
 }
 

@@ -883,6 +883,91 @@ __global__ __launch_bounds__(64) void k_pack(int DPW, int NW, const double *lu, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_pack64: k_pack for R = 64 (one chain per workgroup, K > 32).
+//  * the 64 x 64 unit-triangular diagonal block sits in LDS as one square and is inverted IN PLACE (row q of the inverse
+//    overwrites row q of the block as soon as every lane has used it): 32 KiB per wave instead of the generic kernel's
+//    two squares, i.e. 5 waves per CU instead of 2 -- the generic kernel was the largest item of setup;
+//  * D^{-1}U is handled by the same routine on flipped indices (an upper triangle read back to front is a lower one);
+//  * the tile is written with lane = tile row, one 16-byte store per lane and (wave, i) pair: 1 KiB contiguous per
+//    instruction, every entry of the tile exactly once (zeros included).
+// (A variant with the inverse's column in 64 registers and a fully unrolled substitution was tried: the 2016 independent
+//  multiplier reads get hoisted above the serial FMA chain and spill ~7000 registers; measured 107 ms.)
+// ------------------------------------------------------------------------------------------
+template <bool UPPER>
+__device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const double *lu, int64_t ld, int K,
+                                            const ChainDesc &cd, int sb, double *T, double *dinv)
+{
+    constexpr int R = 64;
+    const int lane = threadIdx.x;
+    const int r = UPPER ? R - 1 - lane : lane;                 // block row this lane stands for
+    const int64_t i0 = cd.row0 + (int64_t)sb * R;
+    const int rows_here = (cd.nrows - sb * R) < R ? (cd.nrows - sb * R) : R;
+    const bool rowok = r < rows_here;
+    const int Kn = K < R - 1 ? K : R - 1;
+    double di = 1.0;
+    if (UPPER && rowok) {
+        di = 1.0 / lu[(int64_t)K * ld + i0 + r];
+        dinv[i0 + r] = di;
+    }
+    // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER)
+    for (int c = 0; c < R; ++c) {
+        const int d = lane - c;   // > 0 below the diagonal
+        double v = 0.0;
+        if (d > 0 && d <= Kn && rowok) {
+            if (!UPPER) v = lu[(int64_t)(K - d) * ld + i0 + r];
+            else if (r + d < rows_here) v = lu[(int64_t)(K + d) * ld + i0 + r] * di;
+        }
+        Ms[lane * R + c] = v;
+    }
+    WAVE_LDS_FENCE();
+    // X = M^{-1}, lane = column j of X: X[q][j] = delta_qj - sum_{c<q} M[q][c] X[c][j]; row q of X replaces row q of M
+    for (int q = 0; q < R; ++q) {
+        double acc0 = (q == lane) ? 1.0 : 0.0, acc1 = 0.0;
+        const double *mq = Ms + q * R;
+        int c = 0;
+        for (; c + 1 < q; c += 2) {
+            acc0 = fma(-mq[c], Ms[c * R + lane], acc0);
+            acc1 = fma(-mq[c + 1], Ms[(c + 1) * R + lane], acc1);
+        }
+        if (c < q) acc0 = fma(-mq[c], Ms[c * R + lane], acc0);
+        WAVE_LDS_FENCE();  // every lane has read row q of M
+        Ms[q * R + lane] = acc0 + acc1;
+        WAVE_LDS_FENCE();
+    }
+    // tile rows: lane = tile lane; entry d: in-block (d <= lane) = -X[lane][lane-d], else the band entry d rows/columns away
+    const int NLD = DPW / 2;
+    d2 *T2 = reinterpret_cast<d2 *>(T);
+    auto val = [&](int d) -> double {
+        if (d <= lane) return -Ms[lane * R + (lane - d)];
+        if (d > K || !rowok) return 0.0;
+        if (!UPPER) return ((int64_t)sb * R + r - d >= 0) ? lu[(int64_t)(K - d) * ld + i0 + r] : 0.0;
+        return ((int64_t)sb * R + r + d < cd.nrows) ? lu[(int64_t)(K + d) * ld + i0 + r] * di : 0.0;
+    };
+    for (int w = 0; w < NW; ++w)
+        for (int i = 0; i < NLD; ++i) {
+            const int d0 = w * DPW + 1 + 2 * i;
+            d2 v;
+            v.x = val(d0);
+            v.y = val(d0 + 1);
+            T2[(int64_t)(w * NLD + i) * 64 + lane] = v;
+        }
+}
+
+__global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, const double *lu, int64_t ld, int K, const ChainDesc *chains,
+                                               const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
+{
+    __shared__ double Ms[64 * 64];
+    const int sb = blockIdx.x, p = blockIdx.y;
+    const ChainDesc cd = chains[p];
+    if (sb >= cd.nsteps) return;
+    const GroupDesc gd = groups[p];
+    const int64_t tdbl = (int64_t)NW * DPW * 64;
+    pack64_side<false>(Ms, DPW, NW, lu, ld, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
+    WAVE_LDS_FENCE();
+    pack64_side<true>(Ms, DPW, NW, lu, ld, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
+}
+
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
                        const GroupDesc *groups, int nchains, int64_t maxsteps, const int64_t *, double *Lt, double *Ut,
                        double *dinv, hipStream_t st)
@@ -894,7 +979,7 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
     case 8: hipLaunchKernelGGL((k_pack<8>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 16: hipLaunchKernelGGL((k_pack<16>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 32: hipLaunchKernelGGL((k_pack<32>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
-    case 64: hipLaunchKernelGGL((k_pack<64>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    case 64: hipLaunchKernelGGL(k_pack64, grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1075,12 +1075,9 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
     hipStream_t st = h->stream;
     const int64_t n = h->op_n > 0 ? h->op_n : h->n;
     const int m = restart;
-    // Basis vectors n doubles apart would, for n a power of two, start on the same HBM channel and bank: a multi-vector
-    // pass then streams its j+2 vectors through ONE channel at a time.  The leading dimension is padded off the
-    // power-of-two grid (SPIKE_GMRES_PAD overrides, in doubles; measurement hook).
-    int64_t pad = 544;
-    if (const char *e = getenv("SPIKE_GMRES_PAD")) pad = atoll(e);
-    const int64_t ldv = n + pad;
+    // leading dimension of the Krylov basis (padding it off the power-of-two grid was measured: no effect on this chip,
+    // the multi-vector kernels are limited by how many pages a CU touches per trip, see spike_krylov.hip)
+    const int64_t ldv = n;
     if (h->gm_restart != m || h->gm_ldv != ldv) {
         auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
         F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);

@@ -71,3 +71,14 @@ def test_bench_row_split_is_block_aligned():
         for w in (1, 2, 4, 8):
             c = row_split(N, w)
             assert c[0] == 0 and c[-1] == N and all(x % 64 == 0 for x in c[:-1]) and sorted(c) == c
+
+
+def test_bench_algorithmic_bytes_match_the_survey_figures():
+    """BYTES(4M,128,1) = 8 623 489 024 + 67 108 864 = 8 690 597 888 B per pass; the reduced-system term is
+    (P-1)*[(2K)^2 + 2*(2K)]*8"""
+    import bench
+    N, K = 4 * 2 ** 20, 128
+    assert bench.alg_bytes(N, K, 1, 1, coupled=False) == 8690597888
+    assert bench.alg_bytes(N, K, 2, 1, coupled=False) == 2 * 8690597888
+    assert bench.alg_bytes(N, K, 1, 64, coupled=True) - 8690597888 == 63 * ((2 * K) ** 2 + 4 * K) * 8
+    assert bench.HBM_PEAK_GBPS == 8000.0

@@ -130,7 +130,7 @@ int spike_apply(spike_handle h, const double *x, double *y, int on_device);
 /* Left-preconditioned GMRES(restart) on the band given at setup (keep_band=1) with this handle
  * as preconditioner (use_pc=0: unpreconditioned).  b,x device pointers of n_local doubles; x
  * holds the initial guess on entry.  Convergence: preconditioned residual <= rtol * initial.
- * Returns 0 converged, 1 hit maxit, <0 error.                                              */
+ * restart <= 64.  Returns 0 converged, 1 hit maxit, <0 error.                              */
 int spike_gmres(spike_handle h, const double *b, double *x, int restart, double rtol, int maxit, int use_pc,
                 int *iters, double *rnorm, double *solve_ms);
 

@@ -1069,6 +1069,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
                            int *iters, double *rnorm, double *solve_ms)
 {
     if (!h || !b || !x || restart < 1 || maxit < 0) return SPIKE_ERR_ARG;
+    if (restart > 64) return fail(h, SPIKE_ERR_ARG, "spike_gmres: restart %d > 64 (the fused update kernel holds 64 coefficients)", restart);
     if (use_pc && !h->ready) return fail(h, SPIKE_ERR_STATE, "spike_gmres with use_pc needs a setup");
     if (h->op_n == 0 && (!h->ready || !h->dA)) return fail(h, SPIKE_ERR_STATE, "spike_gmres needs an operator: the band kept at setup or spike_set_operator_csr");
     if (h->op_n > 0 && h->ready && h->op_n != h->n) return fail(h, SPIKE_ERR_ARG, "operator has %lld rows, preconditioner %lld", (long long)h->op_n, (long long)h->n);

@@ -82,3 +82,10 @@ def test_bench_algorithmic_bytes_match_the_survey_figures():
     assert bench.alg_bytes(N, K, 2, 1, coupled=False) == 2 * 8690597888
     assert bench.alg_bytes(N, K, 1, 64, coupled=True) - 8690597888 == 63 * ((2 * K) ** 2 + 4 * K) * 8
     assert bench.HBM_PEAK_GBPS == 8000.0
+
+
+def test_bench_metric_is_the_baseline_metric():
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert bench.BASELINE_METRIC == json.load(open(os.path.join(root, "BASELINE.json")))["metric"]

@@ -346,3 +346,27 @@ def test_gmres_refinement_types_and_bitwise_reproducibility(spike, oracle, torch
     x = torch.zeros(N, dtype=torch.float64, device="cuda")
     it, rn, ms, ok = sp.gmres(b, x, restart=5, rtol=1e-9, maxit=400, use_pc=False)
     assert ok and it > 5 and _rel(x.cpu().numpy(), u) <= 1e-6
+
+
+@pytest.mark.parametrize("restart", [1, 2, 33, 64])
+def test_gmres_restart_lengths(spike, oracle, torch_cuda, restart):
+    """restart lengths around the 32-vector reduction launch and the 64-coefficient update kernel; > 64 is refused"""
+    torch = torch_cuda
+    N, K, P = 6000, 5, 4
+    A = oracle.gen_band(N, K, delta=1.3)
+    A2 = oracle.gen_band(N, K, delta=0.7)
+    u = oracle.gen_vec(N, seed=9)
+    sp = spike.Spike(partitions=P).setup_band(A)
+    sp.set_operator_band(torch.from_numpy(A2).cuda())
+    b = sp.operator_matvec(torch.from_numpy(u).cuda())
+    x = torch.zeros(N, dtype=torch.float64, device="cuda")
+    it, rn, ms, ok = sp.gmres(b, x, restart=restart, rtol=1e-10, maxit=2000)
+    assert ok, (it, rn)
+    assert _rel(x.cpu().numpy(), u) <= 1e-6
+    # unpreconditioned with a long basis: every reduction width up to restart+2 is exercised
+    x.zero_()
+    it, rn, ms, ok = sp.gmres(b, x, restart=restart, rtol=1e-8, maxit=4000, use_pc=False)
+    if restart >= 33:
+        assert ok and it > 33 and _rel(x.cpu().numpy(), u) <= 1e-5
+    with pytest.raises(Exception):
+        sp.gmres(b, x, restart=65, rtol=1e-8, maxit=10)

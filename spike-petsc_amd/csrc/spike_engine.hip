@@ -110,6 +110,7 @@ struct spike_handle_s {
     std::vector<ChainDesc> chains;
     std::vector<GroupDesc> groups;
     int64_t ntiles = 0, maxsteps = 0;
+    int max_chain_rows = 0;     // longest chain (the fused tridiagonal solve keeps a whole chain in registers)
     size_t factor_doubles = 0;  // doubles of packed L factors (= of packed U factors) one sweep streams
     int nif = 0;
     // device buffers
@@ -443,6 +444,8 @@ static int build_chains(spike_handle h)
     }
     h->ntiles = t0;
     h->maxsteps = ms;
+    h->max_chain_rows = 0;
+    for (int p = 0; p < P; ++p) h->max_chain_rows = std::max<int>(h->max_chain_rows, h->chains[p].nrows);
     return SPIKE_OK;
 }
 
@@ -471,8 +474,16 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
         if (start) (void)hipEventRecord(h->evs[h->nev].first, h->stream);
         else { (void)hipEventRecord(h->evs[h->nev].second, h->stream); ++h->nev; }
     };
-    rec(true);
     const int tag = h->ready ? 0 : 1;  // setup (spike solves) vs PCApply: distinct kernel names in a trace
+    if (h->cfg.scan && h->max_chain_rows <= 64 * 64) {
+        // tridiagonal chains of at most 4096 rows: both sweeps in one launch, the intermediate vector stays in registers
+        a.out = out;
+        rec(true);
+        HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, h->stream, tag));
+        rec(false);
+        return SPIKE_OK;
+    }
+    rec(true);
     if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, h->stream, tag));
     else HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream, tag));
     rec(false);

@@ -81,6 +81,8 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
 hipError_t launch_pack_scan(const double *lu, int64_t ld, const ChainDesc *chains, int nchains, double *l, double *c,
                             double *dinv, hipStream_t st);
 hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag = 0);
+// both sweeps in one launch, the intermediate vector in registers (chains of at most 4096 rows); a.tiles = l, cu = c
+hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, const double *cu, hipStream_t st, int tag = 0);
 hipError_t launch_absmax_diag(const double *band, int64_t ld, int K, int64_t n, double *out, hipStream_t st);
 hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
                            int64_t ld, hipStream_t st);

@@ -429,6 +429,101 @@ __global__ __launch_bounds__(256) void k_scan_sweep(SweepArgs s)
     }
 }
 
+// suffix form of affine_scan64 (the backward recurrence runs from the last lane to the first)
+__device__ __forceinline__ void affine_scan64_rev(double &a, double &b, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ad = __shfl_down(a, off), bd = __shfl_down(b, off);
+        if (lane + off < 64) { b = fma(a, bd, b); a *= ad; }
+    }
+}
+
+// k_scan_solve: forward AND backward sweep of a tridiagonal chain in ONE launch.  The forward result of a whole chain
+// (up to MAXSEG 64-row segments) stays in the wave's registers -- one value per lane and segment -- and the backward
+// recurrence, a suffix scan over the same segments in reverse order, consumes it from there: the intermediate vector
+// never goes to HBM.  Traffic = l, f, 1/u, c in + x out = 40 B/row, exactly the algorithmic bytes of a tridiagonal
+// solve (3 band entries + rhs + solution), against 56 B/row for two k_scan_sweep launches.
+template <int MAXSEG, int TAG>
+__global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *cu)
+{
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= s.nchains) return;
+    const ChainDesc cd = s.chains[p];
+    const double *lcoef = s.tiles;
+    const int nseg = (cd.nrows + 63) / 64;   // host guarantees nseg <= MAXSEG
+    double y[MAXSEG];
+    double carry = 0.0;
+#pragma unroll
+    for (int sg = 0; sg < MAXSEG; sg += U) {
+        if (sg < nseg) {
+            double a[U], b[U], dv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = (sg + u) * 64 + lane;
+                const bool act = rl < cd.nrows;
+                const int64_t gi = cd.row0 + (act ? rl : 0);   // clamped: unconditional loads
+                a[u] = -lcoef[gi];
+                b[u] = s.in[gi];
+                dv[u] = s.dinv[gi];
+                if (!act) { a[u] = 0.0; b[u] = 0.0; dv[u] = 1.0; }
+                if (s.corr_top != nullptr && act) {
+                    if (rl == 0) b[u] -= s.corr_top[p];
+                    if (rl == cd.nrows - 1) b[u] -= s.corr_bot[p];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) affine_scan64(a[u], b[u], lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double g = fma(a[u], carry, b[u]);
+                carry = __shfl(g, 63);
+                y[sg + u] = g * dv[u];
+            }
+        }
+    }
+    carry = 0.0;
+#pragma unroll
+    for (int sg = MAXSEG - U; sg >= 0; sg -= U) {
+        if (sg < nseg) {
+            double a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rl = (sg + u) * 64 + lane;
+                const bool act = rl < cd.nrows;
+                a[u] = -cu[cd.row0 + (act ? rl : 0)];
+                if (!act) { a[u] = 0.0; y[sg + u] = 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) affine_scan64_rev(a[u], y[sg + u], lane);
+#pragma unroll
+            for (int u = U - 1; u >= 0; --u) {
+                const double x = fma(a[u], carry, y[sg + u]);
+                carry = __shfl(x, 0);
+                const int rl = (sg + u) * 64 + lane;
+                if (rl < cd.nrows) s.out[cd.row0 + rl] = x;
+            }
+        }
+    }
+}
+
+// forward + backward in one launch when every chain fits the register-resident form (max_rows <= 64 segments)
+hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, const double *cu, hipStream_t st, int tag)
+{
+    if (nchains <= 0) return hipSuccess;
+    const dim3 g((nchains + 3) / 4), b(256);
+    if (max_rows <= 32 * 64) {
+        if (tag == 0) hipLaunchKernelGGL((k_scan_solve<32, 0>), g, b, 0, st, a, cu);
+        else hipLaunchKernelGGL((k_scan_solve<32, 1>), g, b, 0, st, a, cu);
+    } else if (max_rows <= 64 * 64) {
+        if (tag == 0) hipLaunchKernelGGL((k_scan_solve<64, 0>), g, b, 0, st, a, cu);
+        else hipLaunchKernelGGL((k_scan_solve<64, 1>), g, b, 0, st, a, cu);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag)
 {
     if (nchains <= 0) return hipSuccess;

@@ -377,13 +377,40 @@ hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const 
 // One wave per chain, eight 64-row segments in flight per iteration.  HBM-bound: 32 B/row forward (l, f, 1/u, y),
 // 24 B/row backward (c, y, x) -- against 104 B/row when a tridiagonal system is streamed as 4-diagonal tiles.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void affine_scan64(double &a, double &b, int lane)
+// Cross-lane moves of the scan are DPP modifiers on VALU moves (row_shr inside a 16-lane row, row_bcast:15 / row_bcast:31
+// across rows -- the GFX9 wave-scan idiom), not LDS-crossbar shuffles: a lane without a source keeps `old`, which is the
+// identity map (a = 1, b = 0), so the combine needs no per-lane condition.  With __shfl_up (ds_bpermute) the 24 crossbar
+// operations per 64-row segment kept the LDS pipe busier than HBM.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_move(double old, double src)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double au = __shfl_up(a, off), bu = __shfl_up(b, off);
-        if (lane >= off) { b = fma(a, bu, b); a *= au; }
-    }
+    const int rl = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROWMASK, 0xF, false);
+    const int rh = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(rh, rl);
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void affine_scan_step(double &a, double &b)
+{
+    const double au = dpp_move<CTRL, ROWMASK>(1.0, a), bu = dpp_move<CTRL, ROWMASK>(0.0, b);
+    b = fma(a, bu, b);
+    a *= au;
+}
+
+__device__ __forceinline__ void affine_scan64(double &a, double &b, int /*lane*/)
+{
+    affine_scan_step<0x111, 0xF>(a, b);  // row_shr:1
+    affine_scan_step<0x112, 0xF>(a, b);  // row_shr:2
+    affine_scan_step<0x114, 0xF>(a, b);  // row_shr:4
+    affine_scan_step<0x118, 0xF>(a, b);  // row_shr:8
+    affine_scan_step<0x142, 0xA>(a, b);  // row_bcast:15 into rows 1 and 3
+    affine_scan_step<0x143, 0xC>(a, b);  // row_bcast:31 into rows 2 and 3
+}
+
+// value of lane 63, in scalar registers (the carry between segments)
+__device__ __forceinline__ double last_lane(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 template <bool REV, int TAG>
@@ -423,25 +450,15 @@ __global__ __launch_bounds__(256) void k_scan_sweep(SweepArgs s)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const double g = fma(a[u], carry, b[u]);
-            carry = __shfl(g, 63);
+            carry = last_lane(g);
             if (act[u]) s.out[gi[u]] = REV ? g : g * dv[u];
         }
     }
 }
 
-// suffix form of affine_scan64 (the backward recurrence runs from the last lane to the first)
-__device__ __forceinline__ void affine_scan64_rev(double &a, double &b, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double ad = __shfl_down(a, off), bd = __shfl_down(b, off);
-        if (lane + off < 64) { b = fma(a, bd, b); a *= ad; }
-    }
-}
-
 // k_scan_solve: forward AND backward sweep of a tridiagonal chain in ONE launch.  The forward result of a whole chain
 // (up to MAXSEG 64-row segments) stays in the wave's registers -- one value per lane and segment -- and the backward
-// recurrence, a suffix scan over the same segments in reverse order, consumes it from there: the intermediate vector
+// recurrence -- the same prefix scan with the lanes of a segment in reverse order -- consumes it from there: the intermediate vector
 // never goes to HBM.  Traffic = l, f, 1/u, c in + x out = 40 B/row, exactly the algorithmic bytes of a tridiagonal
 // solve (3 band entries + rhs + solution), against 56 B/row for two k_scan_sweep launches.
 template <int MAXSEG, int TAG>
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double g = fma(a[u], carry, b[u]);
-                carry = __shfl(g, 63);
+                carry = last_lane(g);
                 y[sg + u] = g * dv[u];
             }
         }
@@ -488,21 +505,22 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 #pragma unroll
     for (int sg = MAXSEG - U; sg >= 0; sg -= U) {
         if (sg < nseg) {
-            double a[U];
+            double a[U], b[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int rl = (sg + u) * 64 + lane;
+                const int rl = (sg + u) * 64 + 63 - lane;        // lanes in reverse row order: the recurrence runs upward
                 const bool act = rl < cd.nrows;
                 a[u] = -cu[cd.row0 + (act ? rl : 0)];
-                if (!act) { a[u] = 0.0; y[sg + u] = 0.0; }
+                b[u] = __shfl(y[sg + u], 63 - lane);             // the forward value of row rl sits in lane 63 - lane
+                if (!act) { a[u] = 0.0; b[u] = 0.0; }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) affine_scan64_rev(a[u], y[sg + u], lane);
+            for (int u = 0; u < U; ++u) affine_scan64(a[u], b[u], lane);
 #pragma unroll
             for (int u = U - 1; u >= 0; --u) {
-                const double x = fma(a[u], carry, y[sg + u]);
-                carry = __shfl(x, 0);
-                const int rl = (sg + u) * 64 + lane;
+                const double x = fma(a[u], carry, b[u]);
+                carry = last_lane(x);
+                const int rl = (sg + u) * 64 + 63 - lane;
                 if (rl < cd.nrows) s.out[cd.row0 + rl] = x;
             }
         }

@@ -553,6 +553,16 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     free_factors(h);
     TmpPool tmp;
     const auto t_start = std::chrono::steady_clock::now();
+    // SPIKE_SETUP_TRACE=1: wall time of every setup phase on stderr (synchronises the stream at phase boundaries)
+    const bool trace = getenv("SPIKE_SETUP_TRACE") != nullptr;
+    auto t_mark = t_start;
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(h->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[spike setup] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    };
     h->cfg = cfg;
     h->n_global = n_global; h->row0 = row0; h->n = n; h->K = K;
     h->P_user = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n);
@@ -591,6 +601,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipMemcpyAsync(h->dChains, h->chains.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), hipMemcpyHostToDevice, st));
 
+    mark("band copy");
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
     double *dScal = nullptr;
     HIPCHK(tmp.alloc(&dScal, 2));
@@ -601,6 +612,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipStreamSynchronize(st));
     const double boost = h->boost_rel * dmax;
 
+    mark("boost threshold");
     // LU (scratch copy), then pack into sweep tiles
     double *dLU = nullptr;
     HIPCHK(tmp.alloc(&dLU, (size_t)nd * n));
@@ -608,6 +620,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
     HIPCHK(launch_factor(dLU, n, K, h->dChains, P, boost, dNb, st));
+    mark("LU copy + factor");
     // scan path (K = 1): "tiles" are plain per-row arrays, dLt = l, dUt = c
     const size_t tile_total = cfg.scan ? (size_t)n : (size_t)h->ntiles * (size_t)cfg.tile_doubles();
     h->factor_doubles = tile_total;
@@ -627,6 +640,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     tmp.release(dLU);
     tmp.release(dScal);
 
+    mark("pack");
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
     const bool multi = exchanging(h);
     const int nif_local = P - 1;
@@ -677,6 +691,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
         }
+        mark("spike reach probe");
         if (h->S > 1) {
             // do the spikes die (below spike_tol of their peak) before they reach the far end of the shortest chain?
             double bad = ((int64_t)(extent * 1.06) + K > nmin) ? 1.0 : 0.0;
@@ -743,6 +758,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 subBot.chains = dSubC[1]; subBot.groupsF = dSubG[2]; subBot.groupsB = dSubG[3];
             }
         }
+        mark("sub-chain descriptors");
         // The 2K spike columns are solved SWEEP_MULTI_NR at a time (k_sweep_multi: a factor tile is read once for the
         // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
         const bool batched = cfg.R == 64 && !cfg.scan;
@@ -776,6 +792,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             }
         }
         if (batched) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
+        mark("spike solves");
         h->profile = keep_prof;
         if (m > 0) {
             double stat[2] = {0, 0};
@@ -831,6 +848,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 HIPCHK(hipMemcpyAsync(dVif + (size_t)ib_next * kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
             }
         }
+        mark("coupling blocks + exchange");
         HIPCHK(launch_iface_setup(K, nif, dWif, dVif, h->dWT, h->dVT, h->dST, dWork, dFlag, st));
         std::vector<int> flags(nif, 0);
         HIPCHK(hipMemcpyAsync(flags.data(), dFlag, sizeof(int) * nif, hipMemcpyDeviceToHost, st));
@@ -839,6 +857,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         for (int i = 0; i < nif; ++i)
             if (flags[i]) return fail(h, SPIKE_ERR_SINGULAR, "interface system %d is singular", i);
 
+        mark("interface inverses");
         std::vector<IfaceDesc> ifs(nif);
         for (int i = 0; i < nif_local; ++i) {
             IfaceDesc &d = ifs[i];
@@ -907,6 +926,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         }
         HIPCHK(hipStreamSynchronize(st));
     }
+    mark("interface descriptors");
     if (multi && !h->dSend) {
         HIPCHK(dalloc(&h->dSend, (size_t)2 * (K > 0 ? K : 1)));
         HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * 2 * (K > 0 ? K : 1)));

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--delta", type=float, default=1.2)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --n rows PER GPU, the partitions of every GPU are independent units; strong: --n rows in total")
+    ap.add_argument("--subsplit", default="auto", choices=["auto", "off"],
+                    help="auto (library default): a caller-chosen --partitions may be swept as several chains each; off: one chain per partition")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ksp", action="store_true")
     ap.add_argument("--ksp-iters", type=int, default=30)
@@ -160,6 +162,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sp.set_option("keep_band", 1)
+    sp.set_option("subsplit", args.subsplit)
     sp.setup_band(band, n_global=N, row0=r0)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0

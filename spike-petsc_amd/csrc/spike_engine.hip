@@ -396,7 +396,13 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
     const int64_t nblk = (n + BLK - 1) / BLK;
     int64_t minrows = (int64_t)16 * K;  // spikes of the synthetic dominant systems die out over ~10 K rows
     if (minrows < 512) minrows = 512;
-    int64_t target = (int64_t)(2048 / cfg.NW) * cfg.CPW();  // ~8 waves on each of 256 CUs
+    // Workgroups in whole multiples of the CU count (balance), at least 4 waves per CU (two tiles in flight per wave
+    // already cover the memory latency).  Every interface costs spike and interface traffic, so FEWER chains is
+    // better as long as the sweeps stay at full bandwidth -- measured at N = 4M (ms per coupled apply, half / this many
+    // chains / twice): K=16 -/0.314/0.372, K=32 -/0.516/0.626, K=64 -/0.896/0.927, K=96 1.359/1.294/-,
+    // K=128 2.280/1.496/1.646, K=192 3.210/2.413/-, K=256 3.975/3.069/-.
+    const int64_t ncu = 256;
+    int64_t target = ncu * ((4 + cfg.NW - 1) / cfg.NW) * cfg.CPW();
     if (cfg.scan) target = 8192;  // one light wave per chain: 32 waves per CU keep enough loads in flight
     int64_t byrows = n / minrows;
     int64_t P = target < byrows ? target : byrows;

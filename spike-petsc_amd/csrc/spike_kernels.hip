@@ -17,7 +17,6 @@
 //  * the right-hand-side window lives in LDS (2-3 KiB); band data never touches LDS: it is
 //    used once, straight from VGPRs, with the next step's tile already in flight.
 #include "spike_internal.h"
-#include <cstdlib>
 
 namespace spike {
 
@@ -1619,10 +1618,7 @@ hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchai
                                 const double *xb, const double *xt, double *x, hipStream_t st)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
-    // 64 threads = 128 rows per workgroup (SPIKE_CORRECT_BLOCK overrides: measurement hook)
-    int bs = 64;
-    if (const char *e = getenv("SPIKE_CORRECT_BLOCK")) bs = atoi(e);
-    hipLaunchKernelGGL(k_spike_correct, dim3((m + 2 * bs - 1) / (2 * bs), nchains, 2), dim3(bs), (size_t)K * sizeof(double), st, K, m,
+    hipLaunchKernelGGL(k_spike_correct, dim3((m + 511) / 512, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
                        chains, Wf, Vf, xb, xt, x);
     return hipGetLastError();
 }

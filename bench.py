@@ -60,6 +60,8 @@ def cpu_baseline(K, rows_per_part, variant, budget_rows=None, max_parts=64):
         L = O.lib()
     # the oracle is parallel over partitions: give every host thread one (up to max_parts), same rows/partition as the GPU
     nthreads = int(L.orc_num_threads())
+    rows_gpu = rows_per_part
+    rows_per_part = min(rows_per_part, 8192)   # bounded sample: the oracle's setup is O(rows * K^2) per partition
     P = max(1, min(nthreads, max_parts)) if budget_rows is None else max(1, budget_rows // rows_per_part)
     while P > 1 and P * rows_per_part * (2 * K + 1) * 8 > 3 * 2 ** 30:   # bounded sample: at most 3 GiB of band
         P //= 2
@@ -93,9 +95,9 @@ def cpu_baseline(K, rows_per_part, variant, budget_rows=None, max_parts=64):
     return {
         "value": alg_bytes(N, K, p, P, variant == 1) / per / 1e9, "unit": "GB/s", "cores": min(nthreads, P), "kind": "port",
         "value_one_thread": one,
-        "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition as on the GPU), "
+        "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition; the GPU run has %d), "
                   "%s variant (two passes over the factors), %d applies on %d of %d host threads, setup %.1f s not timed"
-                  % (N, K, P, rows_per_part, "coupled" if variant else "decoupled", reps, min(nthreads, P), nthreads, t_setup),
+                  % (N, K, P, rows_per_part, rows_gpu, "coupled" if variant else "decoupled", reps, min(nthreads, P), nthreads, t_setup),
     }
 
 

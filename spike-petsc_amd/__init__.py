@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "spike_band_matvec", "spike_gen_band", "spike_get_info", "spike_view", "spike_get_tips", "spike_last_sweep_ms",
     "spike_set_operator_csr", "spike_clear_operator", "spike_dev_malloc", "spike_dev_free", "spike_dev_upload",
     "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band", "spike_measure_read_bw",
-    "spike_set_operator_band", "spike_operator_matvec",
+    "spike_set_operator_band", "spike_operator_matvec", "spike_auto_partitions",
 ]
 
 
@@ -78,6 +78,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.spike_create.argtypes = [C.POINTER(vp)]
+    L.spike_auto_partitions.argtypes = [C.c_int, i64]
     L.spike_destroy.argtypes = [vp]
     L.spike_reset.argtypes = [vp]
     L.spike_last_error.argtypes = [vp]

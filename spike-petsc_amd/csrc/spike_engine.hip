@@ -411,6 +411,14 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
     return (int)P;
 }
 
+// host logic only (no device needed): the partition count setup would choose for `partitions = 0`
+extern "C" int spike_auto_partitions(int K, int64_t n_local)
+{
+    SweepCfg cfg;
+    if (n_local <= 0 || !pick_cfg(K, &cfg)) return SPIKE_ERR_ARG;
+    return auto_partitions(cfg, K, n_local);
+}
+
 static int build_chains(spike_handle h)
 {
     const int64_t n = h->n;

@@ -55,3 +55,18 @@ def test_host_band_rule_matches_oracle(spike, oracle):
             k1, f1 = spike.csr_band_k(n, ia, ja, a, kmax, frac)
             k0, f0, *_ = oracle.band_extract(n, ia, ja, a, kmax, frac)
             assert k1 == k0 and f1 == f0  # same order of summation -> bit-identical
+
+
+def test_auto_partition_rule_is_cu_balanced(spike):
+    """partitions = 0: workgroups in whole multiples of the 256 CUs with >= 4 waves per CU (measured table in
+    auto_partitions, spike_engine.hip); host logic, no device needed"""
+    L = spike.lib()
+    N = 4 * 2 ** 20
+    assert L.spike_auto_partitions(128, N) == 256          # headline: one 4-wave workgroup per CU
+    assert L.spike_auto_partitions(256, N) == 256          # 8 waves per chain
+    assert L.spike_auto_partitions(64, N) == 512           # 2 waves per chain -> 2 workgroups per CU
+    assert L.spike_auto_partitions(96, N) == 512
+    assert L.spike_auto_partitions(32, N) == 2048          # 2 chains per wave, 1024 one-wave workgroups
+    assert L.spike_auto_partitions(1, 2 ** 24) == 8192     # scan path
+    assert L.spike_auto_partitions(128, 32768) == 16       # small systems: a partition keeps >= 16 K rows
+    assert L.spike_auto_partitions(300, N) < 0             # K > 256 is refused

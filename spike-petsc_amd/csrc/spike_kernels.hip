@@ -1430,10 +1430,120 @@ __global__ __launch_bounds__(256) void k_iface_setup(int K, const double *Wall, 
     }
 }
 
+// The same for K <= 128 with the whole K x K matrix in LDS (row stride K + 1: conflict-free by rows and by columns;
+// 132 KiB of the CU's 160 KiB at K = 128): S = I - W V is formed there and inverted IN PLACE by Gauss-Jordan with partial
+// pivoting (row swaps recorded, undone as one column permutation when the inverse is written out).  One 1024-thread
+// workgroup per interface, lane = column: a block step touches LDS only -- the global-memory version above moves the
+// augmented K x 2K matrix through L2 once per pivot (8 ms for 255 interfaces at K = 128, against 0.3 ms here).
+__global__ __launch_bounds__(1024) void k_iface_setup_lds(int K, const double *Wall, const double *Vall, double *WTall,
+                                                          double *VTall, double *STall, int *flag)
+{
+    extern __shared__ double sh[];
+    const int LD = K + 1;
+    double *A = sh;                     // K x LD
+    double *rowk = A + (size_t)K * LD;  // K
+    double *colk = rowk + K;            // K
+    double *rmax = colk + K;            // 16 (one per wave)
+    int *ridx = reinterpret_cast<int *>(rmax + 16);  // 16
+    int *perm = ridx + 16;              // K
+    int *cidx = perm + K;               // K
+    __shared__ int s_pr;
+    __shared__ double s_pv;
+    const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t kk = (int64_t)K * K;
+    const double *W = Wall + f * kk, *V = Vall + f * kk;
+    double *WT = WTall + f * kk, *VT = VTall + f * kk, *ST = STall + f * kk;
+    const int c = tid % K, r0 = tid / K, rstep = nt / K;   // thread = (column c, rows r0, r0 + rstep, ...)
+    const bool active = r0 < rstep;                         // the last nt % K threads have no rows
+    // transposes of the inputs (what k_iface_apply streams) and S = I - W V
+    for (int t = tid; t < K * K; t += nt) {
+        const int a = t / K, b = t % K;
+        WT[b * K + a] = W[t];
+        VT[b * K + a] = V[t];
+    }
+    for (int r = active ? r0 : K; r < K; r += rstep) {
+        double acc = (r == c) ? 1.0 : 0.0;
+        for (int k = 0; k < K; ++k) acc = fma(-W[r * K + k], V[k * K + c], acc);
+        A[r * LD + c] = acc;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    for (int k = 0; k < K; ++k) {
+        // pivot search in column k, rows >= k (ties: smallest row, as the global-memory version)
+        double best = -1.0;
+        int bi = K;
+        for (int r = k + tid; r < K; r += nt) {
+            const double v = fabs(A[r * LD + k]);
+            if (v > best) { best = v; bi = r; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_down(best, o);
+            const int oi = __shfl_down(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { rmax[wv] = best; ridx[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double bb = rmax[0];
+            int ii = ridx[0];
+            for (int q = 1; q < nw; ++q)
+                if (rmax[q] > bb || (rmax[q] == bb && ridx[q] < ii)) { bb = rmax[q]; ii = ridx[q]; }
+            s_pr = ii; s_pv = bb; perm[k] = ii;
+        }
+        __syncthreads();
+        const int pr = s_pr;
+        if (!(s_pv > 0.0)) { if (tid == 0) flag[f] = 1; return; }
+        // swap rows k and pr; pivot row scaled, pivot column kept aside
+        if (tid < K) {
+            const double a = A[pr * LD + tid], b = A[k * LD + tid];
+            if (pr != k) A[pr * LD + tid] = b;
+            rowk[tid] = a;
+        }
+        __syncthreads();
+        const double inv = 1.0 / rowk[k];
+        if (tid < K) colk[tid] = (tid == k) ? 0.0 : A[tid * LD + k];
+        __syncthreads();
+        const double rk = (c == k) ? inv : rowk[c] * inv;   // row k of the in-place form: A[k][k] <- 1/pivot
+        if (r0 == 0) A[k * LD + c] = rk;
+        for (int r = active ? r0 : K; r < K; r += rstep)
+            if (r != k) {
+                const double old = (c == k) ? 0.0 : A[r * LD + c];
+                A[r * LD + c] = fma(-colk[r], rk, old);
+            }
+        __syncthreads();
+    }
+    // undo the row swaps: column j of the inverse is column cidx[j] of the in-place result
+    if (tid == 0) {
+        for (int j = 0; j < K; ++j) cidx[j] = j;
+        for (int k = K - 1; k >= 0; --k) { const int p2 = perm[k], t = cidx[k]; cidx[k] = cidx[p2]; cidx[p2] = t; }
+    }
+    __syncthreads();
+    for (int t = tid; t < K * K; t += nt) {
+        const int a = t % K, b = t / K;
+        ST[b * K + a] = A[a * LD + cidx[b]];
+    }
+}
+
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st)
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
+    if (K <= 128) {
+        const int nt = K <= 8 ? 64 : (K <= 32 ? 256 : 1024);
+        const size_t lds = ((size_t)K * (K + 1) + 2 * K + 16) * sizeof(double) + (16 + 2 * (size_t)K) * sizeof(int);
+        static size_t lds_allowed = 48 * 1024;   // beyond this the kernel needs its dynamic-LDS limit raised (once)
+        bool ok = lds <= lds_allowed;
+        if (!ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_iface_setup_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+            lds_allowed = lds;
+            ok = true;
+        }
+        if (!ok) (void)hipGetLastError();   // this device cannot give one workgroup that much LDS: global-memory version
+        if (ok) {
+            hipLaunchKernelGGL(k_iface_setup_lds, dim3(nif), dim3(nt), lds, st, K, W, V, WT, VT, ST, flag);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(k_iface_setup, dim3(nif), dim3(256), (size_t)3 * K * sizeof(double), st, K, W, V, WT, VT, ST,
                        work, flag);
     return hipGetLastError();

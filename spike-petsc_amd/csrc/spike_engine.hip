@@ -643,8 +643,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(dalloc(&h->dDinv, (size_t)n));
     HIPCHK(dalloc(&h->dY, (size_t)n));
     HIPCHK(dalloc(&h->dTmp, (size_t)n));
-    HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
-    HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
+    if (!(cfg.R == 64 && !cfg.scan)) {   // k_pack64 writes every entry of every tile, zeros included
+        HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
+    }
     if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChains, P, h->dLt, h->dUt, h->dDinv, st));
     else HIPCHK(launch_pack(cfg, dLU, n, K, h->dChains, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
     unsigned long long nb = 0;

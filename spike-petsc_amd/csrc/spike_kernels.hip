@@ -1023,48 +1023,63 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const d
         di = 1.0 / lu[(int64_t)K * ld + i0 + r];
         dinv[i0 + r] = di;
     }
-    // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER)
-    for (int c = 0; c < R; ++c) {
-        const int d = lane - c;   // > 0 below the diagonal
-        double v = 0.0;
-        if (d > 0 && d <= Kn && rowok) {
-            if (!UPPER) v = lu[(int64_t)(K - d) * ld + i0 + r];
-            else if (r + d < rows_here) v = lu[(int64_t)(K + d) * ld + i0 + r] * di;
+    // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER).
+    // Loaded one DIAGONAL at a time: the 64 lanes then read 64 consecutive rows of one band diagonal (coalesced);
+    // lane-by-column order would gather 64 different diagonals per instruction.
+    for (int t = lane; t < R * R; t += 64) Ms[t] = 0.0;
+    WAVE_LDS_FENCE();
+    for (int d = 1; d <= Kn; ++d) {
+        if (d <= lane && rowok) {
+            if (!UPPER) Ms[lane * R + lane - d] = lu[(int64_t)(K - d) * ld + i0 + r];
+            else if (r + d < rows_here) Ms[lane * R + lane - d] = lu[(int64_t)(K + d) * ld + i0 + r] * di;
         }
-        Ms[lane * R + c] = v;
     }
     WAVE_LDS_FENCE();
     // X = M^{-1}, lane = column j of X: X[q][j] = delta_qj - sum_{c<q} M[q][c] X[c][j]; row q of X replaces row q of M
     for (int q = 0; q < R; ++q) {
-        double acc0 = (q == lane) ? 1.0 : 0.0, acc1 = 0.0;
+        double acc0 = (q == lane) ? 1.0 : 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         const double *mq = Ms + q * R;
-        int c = 0;
-        for (; c + 1 < q; c += 2) {
-            acc0 = fma(-mq[c], Ms[c * R + lane], acc0);
-            acc1 = fma(-mq[c + 1], Ms[(c + 1) * R + lane], acc1);
+        // chunks of 8 columns with all 16 LDS reads issued before the FMAs.  Columns c >= q of row q are zero (M is
+        // strictly lower), so running a chunk past q multiplies not-yet-inverted rows by zero.
+        for (int c = 0; c < q; c += 8) {
+            double m[8], x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { m[e] = mq[c + e]; x[e] = Ms[(c + e) * R + lane]; }
+            acc0 = fma(-m[0], x[0], acc0); acc1 = fma(-m[1], x[1], acc1); acc2 = fma(-m[2], x[2], acc2); acc3 = fma(-m[3], x[3], acc3);
+            acc0 = fma(-m[4], x[4], acc0); acc1 = fma(-m[5], x[5], acc1); acc2 = fma(-m[6], x[6], acc2); acc3 = fma(-m[7], x[7], acc3);
         }
-        if (c < q) acc0 = fma(-mq[c], Ms[c * R + lane], acc0);
         WAVE_LDS_FENCE();  // every lane has read row q of M
-        Ms[q * R + lane] = acc0 + acc1;
+        Ms[q * R + lane] = (acc0 + acc1) + (acc2 + acc3);
         WAVE_LDS_FENCE();
     }
     // tile rows: lane = tile lane; entry d: in-block (d <= lane) = -X[lane][lane-d], else the band entry d rows/columns away
-    const int NLD = DPW / 2;
+    // Every load is unconditional (clamped address, result selected afterwards) and the 16 entries of a wave slice are
+    // unrolled, so the loads of a slice are in flight together.  (Measured: neither this nor the batched substitution
+    // changes the kernel's 14 ms -- what bounds it is the gather of 257 band diagonals, 512 B from each, per row block.)
+    constexpr int NLD = 16;   // DPW = 32 for every R = 64 configuration
+    (void)DPW;
     d2 *T2 = reinterpret_cast<d2 *>(T);
+    const int64_t rr = i0 + (rowok ? r : 0);
     auto val = [&](int d) -> double {
-        if (d <= lane) return -Ms[lane * R + (lane - d)];
-        if (d > K || !rowok) return 0.0;
-        if (!UPPER) return ((int64_t)sb * R + r - d >= 0) ? lu[(int64_t)(K - d) * ld + i0 + r] : 0.0;
-        return ((int64_t)sb * R + r + d < cd.nrows) ? lu[(int64_t)(K + d) * ld + i0 + r] * di : 0.0;
+        const bool near = d <= lane;
+        const bool far_ok = !near && d <= K && rowok &&
+                            (UPPER ? ((int64_t)sb * R + r + d < cd.nrows) : ((int64_t)sb * R + r - d >= 0));
+        const int dd = far_ok ? d : 0;
+        const double g = lu[(int64_t)(UPPER ? K + dd : K - dd) * ld + rr];
+        const double l = Ms[lane * R + (near ? lane - d : 0)];
+        return near ? -l : (far_ok ? (UPPER ? g * di : g) : 0.0);
     };
-    for (int w = 0; w < NW; ++w)
+    for (int w = 0; w < NW; ++w) {
+        d2 v[NLD];
+#pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int d0 = w * DPW + 1 + 2 * i;
-            d2 v;
-            v.x = val(d0);
-            v.y = val(d0 + 1);
-            T2[(int64_t)(w * NLD + i) * 64 + lane] = v;
+            const int d0 = w * 32 + 1 + 2 * i;
+            v[i].x = val(d0);
+            v[i].y = val(d0 + 1);
         }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) T2[(int64_t)(w * NLD + i) * 64 + lane] = v[i];
+    }
 }
 
 __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, const double *lu, int64_t ld, int K, const ChainDesc *chains,

@@ -394,7 +394,10 @@ static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_
 static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
 {
     const int64_t nblk = (n + BLK - 1) / BLK;
-    int64_t minrows = (int64_t)16 * K;  // spikes of the synthetic dominant systems die out over ~10 K rows
+    // Spikes of diagonally dominant systems die out over ~10-16 K rows.  A chain of 32 K rows keeps the stored part of
+    // its two spikes below about half of the chain, so the coupled variant stays a ONE-pass apply (BASELINE config 2,
+    // N = 1M, K = 32: 1024 chains of 1024 rows 0.179 ms in one pass, 2048 chains of 512 rows 0.233 ms in two).
+    int64_t minrows = (int64_t)32 * K;
     if (minrows < 512) minrows = 512;
     // Workgroups in whole multiples of the CU count (balance), at least 4 waves per CU (two tiles in flight per wave
     // already cover the memory latency).  Every interface costs spike and interface traffic, so FEWER chains is

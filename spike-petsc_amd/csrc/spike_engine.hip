@@ -147,6 +147,8 @@ struct spike_handle_s {
     double *dV = nullptr, *dW = nullptr, *dZ = nullptr, *dDots = nullptr, *dCoef = nullptr, *dRedWs = nullptr;
     int gm_restart = 0;
     int64_t gm_ldv = 0;
+    double *hostDots[2] = {nullptr, nullptr};  // pinned: Hessenberg column of iteration j while iteration j+1 already runs
+    hipEvent_t evDots[2] = {nullptr, nullptr};
     int cgs_refine = 0;  // 0 never (PETSc's default for -ksp_type gmres), 1 ifneeded, 2 always
     // info
     int64_t nboost = 0;
@@ -278,6 +280,7 @@ static void free_factors(spike_handle h)
     F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
     F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
+    for (int i = 0; i < 2; ++i) if (h->hostDots[i]) { (void)hipHostFree(h->hostDots[i]); h->hostDots[i] = nullptr; }
     h->gm_restart = 0;
     h->ready = false;
     h->chains.clear();
@@ -309,6 +312,7 @@ extern "C" int spike_destroy(spike_handle h)
     spike_clear_operator(h);
     if (h->comm && g_rccl.ok()) g_rccl.CommDestroy(h->comm);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int i = 0; i < 2; ++i) if (h->evDots[i]) (void)hipEventDestroy(h->evDots[i]);
     delete h;
     return SPIKE_OK;
 }
@@ -388,7 +392,8 @@ extern "C" int spike_comm_init_local(spike_handle h, int nranks, int rank, int g
     return SPIKE_OK;
 }
 
-static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace = nullptr, double scale = 1.0);
+static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace = nullptr, double scale = 1.0,
+                      const double *scale_norm2_dev = nullptr);
 
 // ---- partitioning ------------------------------------------------------------------------------------
 static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
@@ -541,8 +546,9 @@ __global__ void k_copy_halo(const double *x, int64_t n, int K, double *send)
 // xh = [left halo | x | right halo]; xs != nullptr: x is first scaled by s IN PLACE (xs aliases x: the normalisation of
 // the newest Krylov vector rides on the copy the mat-vec needs anyway)
 __global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv, int rank, int nranks, double *xh,
-                           double *xs, double s)
+                           double *xs, double s, const double *norm2)
 {
+    if (norm2 != nullptr) { const double q = norm2[0]; s = q > 0.0 ? 1.0 / sqrt(q) : 1.0; }   // scale known to the device only
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) {
         double v = x[i];
@@ -1033,11 +1039,11 @@ extern "C" int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunc
 }
 
 // ---- matvec with the kept band ---------------------------------------------------------------------------
-static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace, double scale)
+static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_inplace, double scale, const double *scale_norm2_dev)
 {
     hipStream_t st = h->stream;
     if (h->op_n > 0) {
-        if (scale_inplace) HIPCHK(launch_scale_value(scale_inplace, scale, h->op_n, st));
+        if (scale_inplace) HIPCHK(launch_scale_value(scale_inplace, scale, h->op_n, st, scale_norm2_dev));
         HIPCHK(launch_csr_matvec(h->op_n, h->op_ia, h->op_ja, h->op_a, h->op_tpr, x, y, st));
         return SPIKE_OK;
     }
@@ -1045,11 +1051,11 @@ static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_
     if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
     const bool multi = exchanging(h);
     if (multi && K > 0) {
-        if (scale_inplace) { HIPCHK(launch_scale_value(scale_inplace, scale, h->n, st)); scale_inplace = nullptr; }  // the halo must be scaled too
+        if (scale_inplace) { HIPCHK(launch_scale_value(scale_inplace, scale, h->n, st, scale_norm2_dev)); scale_inplace = nullptr; scale_norm2_dev = nullptr; }  // the halo must be scaled too
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, x, h->n, K, h->dSend);
         { int rc2 = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K); if (rc2) return rc2; }
     }
-    hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh, scale_inplace, scale);
+    hipLaunchKernelGGL(k_build_xh, dim3((unsigned)((std::max<int64_t>(h->n, K) + 255) / 256)), dim3(256), 0, st, x, h->n, K, h->dRecv, h->rank, h->nranks, h->dXh, scale_inplace, scale, scale_inplace ? scale_norm2_dev : nullptr);
     HIPCHK(hipGetLastError());
     if (h->dAtOp && !h->use_kept_band) {
         HIPCHK(launch_band_matvec_tiled(h->n, K, h->dAtOp, h->dXh, y, st));
@@ -1132,6 +1138,11 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
     if (h->gm_restart != m || h->gm_ldv != ldv) {
         auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
         F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
+        for (int i = 0; i < 2; ++i) {
+            if (h->hostDots[i]) (void)hipHostFree(h->hostDots[i]);
+            HIPCHK(hipHostMalloc((void **)&h->hostDots[i], sizeof(double) * ((size_t)m + 3), hipHostMallocDefault));
+            if (!h->evDots[i]) HIPCHK(hipEventCreateWithFlags(&h->evDots[i], hipEventDisableTiming));
+        }
         HIPCHK(dalloc(&h->dRedWs, red_workspace_doubles()));
         HIPCHK(hipMemsetAsync(h->dRedWs, 0, sizeof(double) * red_workspace_doubles(), st));
         HIPCHK(dalloc(&h->dV, (size_t)(m + 1) * ldv));
@@ -1171,11 +1182,20 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
         g[0] = beta;
         int j = 0;
         double pending_scale = 0.0;  // 1/h_{j+1,j} of the newest basis vector: applied by the next mat-vec's copy
+        // refine_never: the operator application of iteration j+1 does not need anything from the host -- the 1/norm of
+        // the new basis vector is read ON THE DEVICE by the mat-vec's copy kernel -- so it is launched BEFORE the host
+        // waits for iteration j's Hessenberg column (pinned buffer + event): the round trip hides behind 3 ms of GPU work.
+        // If iteration j turns out to converge (or ends the cycle), the work launched ahead is simply not used.
+        const bool pipelined = h->cgs_refine == 0;
+        bool ahead = false;
         for (j = 0; j < m && it < maxit; ++j) {
             double *vj = h->dV + (size_t)j * ldv, *vn = h->dV + (size_t)(j + 1) * ldv;
-            if ((rc = matvec_dev(h, vj, h->dW, pending_scale != 0.0 ? vj : nullptr, pending_scale))) return rc;
+            if (!ahead) {
+                if ((rc = matvec_dev(h, vj, h->dW, pending_scale != 0.0 ? vj : nullptr, pending_scale))) return rc;
+                if ((rc = precond(h->dW, vn))) return rc;
+            }
+            ahead = false;
             pending_scale = 0.0;
-            if ((rc = precond(h->dW, vn))) return rc;
             // Classical Gram-Schmidt as PETSc's default for -ksp_type gmres (the reference's options, src/makefile:18):
             // one fused multi-dot pass (VecMDot: the new vector is read once for the whole column), one fused update
             // (VecMAXPY) that also returns the norm of the result (VecNorm) -- two passes over the basis and ONE host
@@ -1189,15 +1209,30 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
                 if ((rc = dist_sum(h, h->dDots, j + 2))) return rc;
                 HIPCHK(launch_axpys_norm(h->dV, ldv, j + 1, h->dDots, vn, n, -1.0, h->dDots + j + 2, h->dRedWs, st));
                 if ((rc = dist_sum(h, h->dDots + j + 2, 1))) return rc;
-                HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 3), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                for (int i = 0; i <= j; ++i) hcol[i] += yv[i];
-                const double before = yv[j + 1], after = yv[j + 2];
+                const double *hb = yv.data();
+                if (pipelined) {
+                    double *pin = h->hostDots[j & 1];
+                    HIPCHK(hipMemcpyAsync(pin, h->dDots, sizeof(double) * (j + 3), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipEventRecord(h->evDots[j & 1], st));
+                    if (j + 1 < m && it + 1 < maxit) {
+                        // V_{j+1} = vn / |vn| on the device (norm^2 at dDots[j+2]), then w = M^{-1} A V_{j+1} -> V_{j+2}
+                        if ((rc = matvec_dev(h, vn, h->dW, vn, 1.0, h->dDots + j + 2))) return rc;
+                        if ((rc = precond(h->dW, h->dV + (size_t)(j + 2) * ldv))) return rc;
+                        ahead = true;
+                    }
+                    HIPCHK(hipEventSynchronize(h->evDots[j & 1]));
+                    hb = pin;
+                } else {
+                    HIPCHK(hipMemcpyAsync(yv.data(), h->dDots, sizeof(double) * (j + 3), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                }
+                for (int i = 0; i <= j; ++i) hcol[i] += hb[i];
+                const double before = hb[j + 1], after = hb[j + 2];
                 hn = std::sqrt(after);
                 const bool again = pass == 0 && (h->cgs_refine == 2 || (h->cgs_refine == 1 && !(after > 0.5 * before)));
                 if (!again) break;
             }
-            if (hn != 0.0) pending_scale = 1.0 / hn;
+            if (hn != 0.0 && !ahead) pending_scale = 1.0 / hn;
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
             H[(size_t)(j + 1) * m + j] = hn;
             for (int i = 0; i < j; ++i) {

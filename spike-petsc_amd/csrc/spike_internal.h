@@ -133,7 +133,7 @@ hipError_t launch_axpys_norm(const double *V, int64_t ldv, int nvec, const doubl
                              double *norm2_out, double *ws, hipStream_t st);
 hipError_t launch_scale_copy(const double *w, const double *scal_dev, int invert, double *out, int64_t n,
                              hipStream_t st);
-hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st);
+hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st, const double *norm2_dev = nullptr);
 hipError_t launch_residual(const double *b, const double *ax, double *r, int64_t n, hipStream_t st);
 hipError_t launch_lincomb(const double *V, int64_t ldv, int nvec, const double *y_dev, double *x, int64_t n,
                           hipStream_t st);

@@ -207,17 +207,19 @@ hipError_t launch_scale_copy(const double *w, const double *scal_dev, int invert
     return hipGetLastError();
 }
 
-__global__ void k_scale_value(double *w, double s, int64_t n)
+// w *= s, or (norm2 != nullptr) w *= 1/sqrt(norm2[0]) with the squared norm read on the device (0 -> no scaling)
+__global__ void k_scale_value(double *w, double s, const double *norm2, int64_t n)
 {
+    if (norm2 != nullptr) { const double q = norm2[0]; s = q > 0.0 ? 1.0 / sqrt(q) : 1.0; }
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) w[r] *= s;
 }
 
-hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st)
+hipError_t launch_scale_value(double *w, double s, int64_t n, hipStream_t st, const double *norm2_dev)
 {
     int grid = (int)((n + 255) / 256);
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_scale_value, dim3(grid), dim3(256), 0, st, w, s, n);
+    hipLaunchKernelGGL(k_scale_value, dim3(grid), dim3(256), 0, st, w, s, norm2_dev, n);
     return hipGetLastError();
 }
 

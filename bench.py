@@ -206,6 +206,17 @@ def main():
 
     read_ceiling = sp.measure_read_bw(10)   # pure read stream over the same factors (GB/s), this device, this run
 
+    # SURVEY.md 8d timing protocol: device time of single applies (events on the stream the library launches on --
+    # the handle uses torch's current stream), median and minimum over the same number of applies; outside the timed region
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 1))]
+    for e0, e1 in evs:
+        e0.record()
+        sp.apply(b, x)
+        e1.record()
+    torch.cuda.synchronize()
+    per_apply = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    apply_ms_median, apply_ms_min = per_apply[len(per_apply) // 2], per_apply[0]
+
     # Krylov: fixed number of left-preconditioned GMRES(30) iterations (rtol=0 so it never stops early)
     ksp = None
     if not args.no_ksp:
@@ -260,6 +271,7 @@ def main():
                        "passes_over_factors": p, "rows_per_partition": n_local // info.P_local,
                        "stored_spike_rows": int(info.spike_rows)},
             "GBps_single_pass_bytes": gbps_1,
+            "apply_ms_median_device": apply_ms_median, "apply_ms_min_device": apply_ms_min,
             "max_abs_error_vs_exact_solution": err,
             "setup_s": setup_s,
             "ksp": ksp,

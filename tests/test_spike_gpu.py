@@ -370,3 +370,17 @@ def test_gmres_restart_lengths(spike, oracle, torch_cuda, restart):
         assert ok and it > 33 and _rel(x.cpu().numpy(), u) <= 1e-5
     with pytest.raises(Exception):
         sp.gmres(b, x, restart=65, rtol=1e-8, maxit=10)
+
+
+@pytest.mark.parametrize("K,P", [(33, 8), (65, 4), (90, 4), (91, 3), (100, 4), (127, 4), (129, 2), (255, 2)])
+def test_odd_half_bandwidths(spike, oracle, torch_cuda, K, P):
+    """half-bandwidths around the configuration boundaries (32/64/96/128/256 streamed diagonals) and around the
+    64-KiB LDS boundary of the in-LDS interface inversion (K = 90 / 91)"""
+    torch = torch_cuda
+    N = 64 * 40 * P
+    band = oracle.gen_band(N, K, delta=0.9)
+    f = oracle.gen_vec(N)
+    sp = spike.Spike(partitions=P, variant="coupled").setup_band(torch.from_numpy(band).cuda())
+    x = sp.apply(torch.from_numpy(f).cuda()).cpu().numpy()
+    xo = oracle.Spike(band, P).apply(f, 1)
+    assert _rel(x, xo) <= 1e-10

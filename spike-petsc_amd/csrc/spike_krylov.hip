@@ -45,8 +45,17 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double *part, int n
     __shared__ double fin[1024];
     constexpr int NCH = 1024 / NV;
     const int i = threadIdx.x % NV, c = threadIdx.x / NV;
+    // fixed order, eight loads in flight: a = (((p0 + p1) + p2) + ...) exactly as a rolled loop would add them
     double a = 0.0;
-    for (int b = c; b < nblocks; b += NCH) a += part[(int64_t)b * NV + i];
+    int b = c;
+    for (; b + 7 * NCH < nblocks; b += 8 * NCH) {
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = part[(int64_t)(b + e * NCH) * NV + i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += v[e];
+    }
+    for (; b < nblocks; b += NCH) a += part[(int64_t)b * NV + i];
     fin[threadIdx.x] = a;
     __syncthreads();
 #pragma unroll

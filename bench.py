@@ -9,10 +9,11 @@ banded system of SURVEY.md 8d (N = 4*2^20, K = 128, delta = 1.2, seed 12345), ge
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU.  SPIKE partitions are the independent units of this path, so by default every GPU
-gets the same number of rows (--n per GPU: "scaling": "weak"; the global system has --n * N rows); --scaling strong
-keeps the total at --n.  Each rank factors its own partitions; the rank-boundary interface systems are assembled by
-an RCCL allgather inside the library (spike_comm_init) -- the only data-path exchange (2K doubles per rank per apply).
+N > 1: one process per GPU.  The metric names ONE system ("N=4M ... 1/2/4/8 GPU"), so the default is
+"scaling": "strong": --n rows IN TOTAL, contiguous row blocks of --n / N rows per GPU.  The weak-scaled figure (--n rows
+PER GPU) is measured in the same run and reported under the extra key "weak" (--scaling weak makes it the main line).
+Each rank factors its own partitions; the rank-boundary interface systems are assembled by an RCCL allgather inside the
+library (spike_comm_init) -- the only data-path exchange (2K doubles per rank per apply).
 
 Algorithmic bytes per PCApply (SURVEY.md 8d / BASELINE.md 3):
     BYTES(N,K,p) = p*[(2K+1)*N*8 + 2*N*8] + (P-1)*[(2K)^2 + 4K]*8      p = 1 decoupled, p = 2 coupled
@@ -50,54 +51,86 @@ def pmc_traffic(N, K, world):
     return None
 
 
-def cpu_baseline(K, rows_per_part, variant, budget_rows=None, max_parts=64):
-    """The oracle (CPU port of the same algorithm) timed on this host, on a bounded sample."""
+def host_cores():
+    """CPUs this process may really use: affinity mask and cgroup quota (a GPU box gives a one-GPU job a share of the
+    host, e.g. 16 of 128 hardware threads; OpenMP's default would oversubscribe it 8x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(N, K, P, variant, tip_rows=2048, setup_budget_s=12.0, apply_budget_s=8.0):
+    """The oracle (CPU port of the same algorithm: oracle/spike_oracle.c) timed on this host with the GPU run's own
+    K and rows per partition, OpenMP over partitions on the host cores this job may use (count printed).  Setup is not
+    timed but must stay bounded: its spike tips come from solves on `tip_rows` rows next to the interfaces (bench only,
+    the tests use the plain setup), and when factoring all P partitions would not fit `setup_budget_s` on this host the
+    sample keeps the first P_s of them (a multiple of the core count; partitions are independent units, so GB/s does not
+    depend on how many there are beyond one per core) and says so."""
     import numpy as np
     import oracle as O
     try:
         L = O.lib(O.build(native=True))
     except Exception:
         L = O.lib()
-    # the oracle is parallel over partitions: give every host thread one (up to max_parts), same rows/partition as the GPU
-    nthreads = int(L.orc_num_threads())
-    rows_gpu = rows_per_part
-    rows_per_part = min(rows_per_part, 8192)   # bounded sample: the oracle's setup is O(rows * K^2) per partition
-    P = max(1, min(nthreads, max_parts)) if budget_rows is None else max(1, budget_rows // rows_per_part)
-    while P > 1 and P * rows_per_part * (2 * K + 1) * 8 > 3 * 2 ** 30:   # bounded sample: at most 3 GiB of band
-        P //= 2
-    N = P * rows_per_part
-    band = O.gen_band(N, K, L=L)
-    f = O.gen_vec(N)
-    t0 = time.perf_counter()
-    sp = O.Spike(band, P, L=L)
-    t_setup = time.perf_counter() - t0
-    sp.apply(f, variant)
-    reps, t = 0, 0.0
-    t0 = time.perf_counter()
-    while reps < 3 or (t < 3.0 and reps < 50):
-        sp.apply(f, variant)
-        reps += 1
-        t = time.perf_counter() - t0
-    per = t / reps
-    p = 2 if variant == 1 else 1
-    # one thread = what a single PETSc rank of the reference does (SURVEY.md 8d); bounded to a few applies
-    one = None
-    try:
-        L.orc_set_num_threads(1)
+    cores = host_cores()
+    L.orc_set_num_threads(cores)
+    rows_per_part = max(N // P, 64)
+    tips = tip_rows if rows_per_part > 2 * tip_rows else 0
+    p = 2 if variant == 1 else 1   # the oracle's coupled variant re-solves: two passes over the factors
+
+    def make(Ps):
         t0 = time.perf_counter()
-        r1 = 0
-        while r1 < 1 or (time.perf_counter() - t0 < 4.0 and r1 < 5):
+        band = O.gen_band(Ps * rows_per_part, K, L=L)
+        sp = O.Spike(band, Ps, L=L, tip_rows=tips)
+        return sp, time.perf_counter() - t0
+
+    P0 = min(P, cores)
+    sp, t_setup = make(P0)            # one partition per core: tells what a round of partitions costs on this host
+    Ps, note = P0, ""
+    if P > P0:
+        rounds = int(setup_budget_s // max(t_setup, 1e-3))
+        if t_setup * (P / P0) <= setup_budget_s:
+            Ps = P
+        elif rounds >= 2:
+            Ps = min(P, P0 * rounds)
+        if Ps != P0:
+            del sp
+            sp, t_setup = make(Ps)
+        if Ps < P:
+            note = (" -- the first %d of the GPU run's %d partitions: factoring all of them (N=%d) would take about %.0f s "
+                    "on this host's %d cores" % (Ps, P, N, t_setup * P / Ps, cores))
+    Ns = Ps * rows_per_part
+    f = O.gen_vec(Ns)
+    t0 = time.perf_counter()
+    sp.apply(f, variant)           # warm-up, also tells how many timed applies fit the budget
+    t_one = time.perf_counter() - t0
+    reps = int(max(2, min(20, apply_budget_s // max(t_one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sp.apply(f, variant)
+    per = (time.perf_counter() - t0) / reps
+    one = None
+    try:   # one thread = what a single PETSc rank of the reference does (SURVEY.md 8d); one apply, bounded
+        if per * cores * 0.7 < apply_budget_s:
+            L.orc_set_num_threads(1)
+            t0 = time.perf_counter()
             sp.apply(f, variant)
-            r1 += 1
-        one = alg_bytes(N, K, p, P, variant == 1) / ((time.perf_counter() - t0) / r1) / 1e9
+            one = alg_bytes(Ns, K, p, Ps, variant == 1) / (time.perf_counter() - t0) / 1e9
     finally:
-        L.orc_set_num_threads(nthreads)
+        L.orc_set_num_threads(cores)
     return {
-        "value": alg_bytes(N, K, p, P, variant == 1) / per / 1e9, "unit": "GB/s", "cores": min(nthreads, P), "kind": "port",
-        "value_one_thread": one,
-        "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition; the GPU run has %d), "
-                  "%s variant (two passes over the factors), %d applies on %d of %d host threads, setup %.1f s not timed"
-                  % (N, K, P, rows_per_part, rows_gpu, "coupled" if variant else "decoupled", reps, min(nthreads, P), nthreads, t_setup),
+        "value": alg_bytes(Ns, K, p, Ps, variant == 1) / per / 1e9, "unit": "GB/s", "cores": min(cores, Ps), "kind": "port",
+        "value_one_thread": one, "N": Ns, "K": K, "partitions": Ps, "rows_per_partition": rows_per_part,
+        "sample": "oracle/spike_oracle.c (OpenMP over partitions), N=%d K=%d P=%d (%d rows/partition, as the GPU run)%s; "
+                  "%s variant (two passes over the factors), %d applies of %.2f s on %d cores (the share of the host's %d "
+                  "hardware threads this job may use), generation+setup %.1f s not timed"
+                  % (Ns, K, Ps, rows_per_part, note, "coupled" if variant else "decoupled", reps, per, min(cores, Ps),
+                     os.cpu_count() or 0, t_setup),
     }
 
 
@@ -111,15 +144,17 @@ def main():
     ap.add_argument("--partitions", type=int, default=0, help="per GPU; 0 = auto")
     ap.add_argument("--variant", default="coupled", choices=["coupled", "decoupled"])
     ap.add_argument("--delta", type=float, default=1.2)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): --n rows PER GPU, the partitions of every GPU are independent units; strong: --n rows in total")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, the metric: ONE system of --n rows over all GPUs); weak: --n rows PER GPU. "
+                         "With more than one GPU the other one is measured too and reported under an extra key")
     ap.add_argument("--subsplit", default="auto", choices=["auto", "off"],
                     help="auto (library default): a caller-chosen --partitions may be swept as several chains each; off: one chain per partition")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ksp", action="store_true")
+    ap.add_argument("--no-extra-scaling", action="store_true", help="N > 1: skip the second (other-scaling) measurement")
     ap.add_argument("--ksp-iters", type=int, default=30)
     ap.add_argument("--ksp-delta", type=float, default=1.0,
-                    help="second KSP measurement on the operator with this diagonal dominance (0 = skip)")
+                    help="KSP operator: same off-diagonals, this diagonal dominance (the PC is built with --delta); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -144,146 +179,164 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def allmax(v):
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     K = args.k
-    N = args.n * world if args.scaling == "weak" else args.n
-    # contiguous row blocks on 64-row boundaries
-    nblk = (N + 63) // 64
-    r0 = (nblk * rank // world) * 64
-    r1 = N if rank == world - 1 else (nblk * (rank + 1) // world) * 64
-    n_local = r1 - r0
-
-    sp = S.Spike(partitions=args.partitions, variant=args.variant, profile=True)
-    if world > 1:
-        uid = torch.zeros(S.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(S.unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(uid, 0)
-        sp.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
-
-    band = S.gen_band_device(N, K, seed=12345, delta=args.delta, row0=r0, nrows=n_local)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sp.set_option("keep_band", 1)
-    sp.set_option("subsplit", args.subsplit)
-    sp.setup_band(band, n_global=N, row0=r0)
-    torch.cuda.synchronize()
-    setup_s = time.perf_counter() - t0
-    del band
-    info = sp.info()
-    P_total = info.P_local * world
-
-    u = torch.ones(n_local, dtype=torch.float64, device="cuda")
-    b = sp.matvec(u)          # rhs = A*1, as /root/reference/src/testbed2.c:120-122
-    x = torch.empty_like(b)
-    for _ in range(args.warmup):
-        sp.apply(b, x)
-    barrier()
-    t0 = time.perf_counter()
-    sweep_ms, sweep_launches = 0.0, 0
-    for _ in range(args.steps):
-        sp.apply(b, x)
-    barrier()
-    dt = time.perf_counter() - t0
-    # kernel time of the LAST apply from HIP events recorded on the handle's stream
-    sweep_ms, sweep_launches = sp.last_sweep_ms()
-    err = float((x - u).abs().max())
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    ms_per_step = dt / args.steps * 1e3
-    p = int(info.passes)          # 1: decoupled, or coupled with stored spikes; 2: coupled re-solving
     coupled = args.variant == "coupled"
-    gbps = alg_bytes(N, K, p, P_total, coupled) / (dt / args.steps) / 1e9
-    gbps_1 = alg_bytes(N, K, 1, P_total, coupled) / (dt / args.steps) / 1e9
 
-    # dominant kernel: k_sweep (forward + backward launch = one pass over the factors of the local rows)
-    n_pass = max(sweep_launches // 2, 1)
-    pass_bytes = (2 * K + 1) * n_local * 8 + 2 * n_local * 8
-    pass_ms = sweep_ms / n_pass if sweep_launches else float("nan")
-    achieved = pass_bytes / (pass_ms * 1e-3) / 1e9 if sweep_launches else float("nan")
+    def measure(N, with_ksp, with_ceiling):
+        """setup + the timed PCApply loop (+ KSP) on one system of N rows over all ranks"""
+        nblk = (N + 63) // 64   # contiguous row blocks on 64-row boundaries
+        r0 = (nblk * rank // world) * 64
+        r1 = N if rank == world - 1 else (nblk * (rank + 1) // world) * 64
+        n_local = r1 - r0
+        sp = S.Spike(partitions=args.partitions, variant=args.variant, profile=True)
+        if world > 1:
+            uid = torch.zeros(S.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(S.unique_id()), dtype=torch.uint8).cuda()
+            dist.broadcast(uid, 0)
+            sp.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        band = S.gen_band_device(N, K, seed=12345, delta=args.delta, row0=r0, nrows=n_local)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sp.set_option("keep_band", 1)
+        sp.set_option("subsplit", args.subsplit)
+        sp.setup_band(band, n_global=N, row0=r0)
+        torch.cuda.synchronize()
+        setup_s = allmax(time.perf_counter() - t0)
+        del band
+        info = sp.info()
+        P_total = info.P_local * world
 
-    read_ceiling = sp.measure_read_bw(10)   # pure read stream over the same factors (GB/s), this device, this run
-
-    # SURVEY.md 8d timing protocol: device time of single applies (events on the stream the library launches on --
-    # the handle uses torch's current stream), median and minimum over the same number of applies; outside the timed region
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 1))]
-    for e0, e1 in evs:
-        e0.record()
-        sp.apply(b, x)
-        e1.record()
-    torch.cuda.synchronize()
-    per_apply = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    apply_ms_median, apply_ms_min = per_apply[len(per_apply) // 2], per_apply[0]
-
-    # Krylov: fixed number of left-preconditioned GMRES(30) iterations (rtol=0 so it never stops early)
-    ksp = None
-    if not args.no_ksp:
-        xg = torch.zeros_like(b)
-        sp.set_option("profile", 0)
-        sp.gmres(b, xg, restart=30, rtol=0.0, maxit=3)  # warm-up (allocates the Krylov basis)
-        xg.zero_()
+        u = torch.ones(n_local, dtype=torch.float64, device="cuda")
+        b = sp.matvec(u)          # rhs = A*1, as /root/reference/src/testbed2.c:120-122
+        x = torch.empty_like(b)
+        for _ in range(args.warmup):
+            sp.apply(b, x)
         barrier()
-        it, rn, ms, ok = sp.gmres(b, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sp.apply(b, x)
         barrier()
-        tk = torch.tensor([ms], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-        ksp = {"iters": it, "solve_ms": float(tk.item()), "iters_per_sec": it / (float(tk.item()) * 1e-3)}
-        # and one real solve to the reference's tolerance (src/makefile:18: rtol 1e-5, max_it 500)
-        xg.zero_()
-        it2, rn2, ms2, ok2 = sp.gmres(b, xg, restart=30, rtol=1e-5, maxit=500)
-        ksp.update({"converged_iters_rtol1e-5": it2, "converged_solve_ms": ms2, "converged": bool(ok2),
-                    "error_inf": float((xg - u).abs().max()),
-                    "note": "iters_per_sec = steady-state rate over a fixed number of left-preconditioned GMRES(30) "
-                            "iterations (rtol 0); the solve to rtol 1e-5 (src/makefile:18) needs converged_iters iterations"})
+        dt = allmax(time.perf_counter() - t0)
+        # kernel time of the LAST apply from HIP events recorded on the handle's stream
+        sweep_ms, sweep_launches = sp.last_sweep_ms()
+        err = allmax(float((x - u).abs().max()))
+        p = int(info.passes)          # 1: decoupled, or coupled with stored spikes; 2: coupled re-solving
+        res = {"N": N, "n_local": n_local, "info": info, "P_total": P_total, "setup_s": setup_s, "dt": dt, "err": err, "passes": p,
+               "ms_per_step": dt / args.steps * 1e3,
+               "gbps": alg_bytes(N, K, p, P_total, coupled) / (dt / args.steps) / 1e9,
+               "gbps_1": alg_bytes(N, K, 1, P_total, coupled) / (dt / args.steps) / 1e9}
+        # dominant kernel: k_sweep (forward + backward launch = one pass over the factors of the local rows)
+        n_pass = max(sweep_launches // 2, 1)
+        res["pass_bytes"] = (2 * K + 1) * n_local * 8 + 2 * n_local * 8
+        res["pass_ms"] = sweep_ms / n_pass if sweep_launches else float("nan")
+        res["achieved"] = res["pass_bytes"] / (res["pass_ms"] * 1e-3) / 1e9 if sweep_launches else float("nan")
+        res["read_ceiling"] = sp.measure_read_bw(10) if with_ceiling else None   # pure read stream over the same factors
+        # SURVEY.md 8d timing protocol: device time of single applies (events on the stream the library launches on --
+        # the handle uses torch's current stream), median and minimum; outside the timed region
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 1))]
+        for e0, e1 in evs:
+            e0.record()
+            sp.apply(b, x)
+            e1.record()
+        torch.cuda.synchronize()
+        per_apply = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        res["apply_ms_median"], res["apply_ms_min"] = per_apply[len(per_apply) // 2], per_apply[0]
 
-    # The same Krylov loop on an operator the preconditioner does NOT invert exactly (the usual case: PC built from a
-    # nearby matrix): A' = the same off-diagonals with diagonal dominance --ksp-delta instead of --delta.
-    if ksp is not None and args.ksp_delta > 0:
-        opband = S.gen_band_device(N, K, seed=12345, delta=args.ksp_delta, row0=r0, nrows=n_local)
-        sp.set_operator_band(opband)
-        del opband
-        b2 = sp.operator_matvec(u)
-        xg.zero_()
-        barrier()
-        itp, rnp, msp, okp = sp.gmres(b2, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
-        barrier()
-        tk = torch.tensor([msp], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
-        xg.zero_()
-        itc, rnc, msc, okc = sp.gmres(b2, xg, restart=30, rtol=1e-5, maxit=500)
-        ksp["nearby_operator"] = {"operator_delta": args.ksp_delta, "iters": itp, "solve_ms": float(tk.item()),
-                                  "iters_per_sec": itp / (float(tk.item()) * 1e-3), "converged_iters_rtol1e-5": itc,
-                                  "converged": bool(okc), "error_inf": float((xg - u).abs().max())}
-        sp.set_operator_band(None)
+        ksp = None
+        if with_ksp:
+            # Left-preconditioned GMRES(30), fixed iteration count (rtol = 0 so it never stops early).  The reported figure
+            # is on an operator the preconditioner does NOT invert exactly -- the usual case (PC from a nearby or lagged
+            # matrix): A' = the same off-diagonals with diagonal dominance --ksp-delta, PC built with --delta.
+            sp.set_option("profile", 0)
+            xg = torch.zeros_like(b)
+            sp.gmres(b, xg, restart=30, rtol=0.0, maxit=3)  # warm-up (allocates the Krylov basis)
+            ksp = {}
+            if args.ksp_delta > 0:
+                opband = S.gen_band_device(N, K, seed=12345, delta=args.ksp_delta, row0=r0, nrows=n_local)
+                sp.set_operator_band(opband)
+                del opband
+                b2 = sp.operator_matvec(u)
+                xg.zero_()
+                barrier()
+                itp, rnp, msp, okp = sp.gmres(b2, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
+                barrier()
+                msp = allmax(msp)
+                xg.zero_()
+                itc, rnc, msc, okc = sp.gmres(b2, xg, restart=30, rtol=1e-5, maxit=500)   # src/makefile:18: rtol 1e-5, max_it 500
+                ksp = {"iters_per_sec": itp / (msp * 1e-3), "iters": itp, "solve_ms": msp, "operator_delta": args.ksp_delta,
+                       "pc_delta": args.delta, "converged_iters_rtol1e-5": itc, "converged_solve_ms": msc, "converged": bool(okc),
+                       "error_inf": float((xg - u).abs().max()),
+                       "note": "iters_per_sec = steady-state rate over a fixed number of left-preconditioned GMRES(30) iterations "
+                               "(rtol 0) on the operator with diagonal dominance operator_delta, preconditioned by SPIKE built "
+                               "from the matrix with pc_delta; the solve to rtol 1e-5 (src/makefile:18) needs converged_iters"}
+                sp.set_operator_band(None)
+            # the same loop on the factored matrix itself (the PC is then the exact inverse: 1 iteration to converge)
+            xg.zero_()
+            barrier()
+            it, rn, ms, ok = sp.gmres(b, xg, restart=30, rtol=0.0, maxit=args.ksp_iters)
+            barrier()
+            ms = allmax(ms)
+            xg.zero_()
+            it2, rn2, ms2, ok2 = sp.gmres(b, xg, restart=30, rtol=1e-5, maxit=500)
+            exact = {"iters": it, "solve_ms": ms, "iters_per_sec": it / (ms * 1e-3), "converged_iters_rtol1e-5": it2,
+                     "converged": bool(ok2), "error_inf": float((xg - u).abs().max())}
+            if ksp:
+                ksp["exact_pc_operator"] = exact
+            else:
+                ksp = exact
+        res["ksp"] = ksp
+        sp.close()
+        return res
+
+    N_main = args.n if args.scaling == "strong" else args.n * world
+    m = measure(N_main, not args.no_ksp, True)
+    extra = None
+    if world > 1 and not args.no_extra_scaling:
+        other = "weak" if args.scaling == "strong" else "strong"
+        N_other = args.n * world if other == "weak" else args.n
+        e = measure(N_other, False, False)
+        extra = {"scaling": other, "N": N_other, "N_per_gpu": e["n_local"], "value": e["gbps"], "unit": "GB/s",
+                 "ms_per_step": e["ms_per_step"], "apply_ms_median_device": e["apply_ms_median"], "partitions": e["P_total"],
+                 "passes_over_factors": e["passes"], "max_abs_error_vs_exact_solution": e["err"], "setup_s": e["setup_s"]}
 
     if rank == 0:
+        info = m["info"]
         out = {
-            "metric": BASELINE_METRIC, "metric_note": "value = PCApply GB/s; KSP iterations/s in ksp.iters_per_sec", "value": gbps, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "metric": BASELINE_METRIC, "metric_note": "value = PCApply GB/s; KSP iterations/s in ksp.iters_per_sec", "value": m["gbps"],
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "banded N=%d half-bw=%d fp64, SPIKE %s, %d partitions (%d/GPU), delta=%.2f, seed 12345"
-                                   % (N, K, args.variant, P_total, info.P_local, args.delta),
-                       "N": N, "N_per_gpu": n_local, "K": K, "partitions": P_total, "variant": args.variant,
-                       "passes_over_factors": p, "rows_per_partition": n_local // info.P_local,
-                       "stored_spike_rows": int(info.spike_rows)},
-            "GBps_single_pass_bytes": gbps_1,
-            "apply_ms_median_device": apply_ms_median, "apply_ms_min_device": apply_ms_min,
-            "max_abs_error_vs_exact_solution": err,
-            "setup_s": setup_s,
-            "ksp": ksp,
+                                   % (m["N"], K, args.variant, m["P_total"], info.P_local, args.delta),
+                       "N": m["N"], "N_per_gpu": m["n_local"], "K": K, "partitions": m["P_total"], "variant": args.variant,
+                       "passes_over_factors": m["passes"], "rows_per_partition": m["n_local"] // info.P_local,
+                       "chains_per_gpu": int(info.chains_local), "stored_spike_rows": int(info.spike_rows)},
+            "GBps_single_pass_bytes": m["gbps_1"],
+            "apply_ms_median_device": m["apply_ms_median"], "apply_ms_min_device": m["apply_ms_min"],
+            "max_abs_error_vs_exact_solution": m["err"],
+            "setup_s": m["setup_s"],
+            "ksp": m["ksp"],
             "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(N, K, world),
-                         "alg_bytes_per_pass": pass_bytes, "pass_ms": pass_ms,
-                         "measured_read_ceiling_GBps": read_ceiling, "frac_of_measured_ceiling": achieved / read_ceiling},
+                         "achieved": m["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": m["achieved"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(m["N"], K, world),
+                         "traffic_source": "static: profiles/pmc_current.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "this command, committed; not re-measured in this run)",
+                         "alg_bytes_per_pass": m["pass_bytes"], "pass_ms": m["pass_ms"],
+                         "measured_read_ceiling_GBps": m["read_ceiling"],
+                         "frac_of_measured_ceiling": m["achieved"] / m["read_ceiling"] if m["read_ceiling"] else None},
         }
+        if extra is not None:
+            out[extra["scaling"]] = extra
         if not args.no_cpu and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(K, max(n_local // info.P_local, 64), 1 if args.variant == "coupled" else 0)
+                out["cpu_baseline"] = cpu_baseline(m["N"], K, info.P_local, 1 if coupled else 0)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

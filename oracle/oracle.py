@@ -50,6 +50,8 @@ def lib(path=None):
     L.orc_band_lusolve.argtypes = [C.c_int, dptr, i64, i64, i64, dptr, dptr]
     L.orc_spike_setup.argtypes = [i64, C.c_int, C.c_int, dptr, i64, C.c_double]
     L.orc_spike_setup.restype = C.c_void_p
+    L.orc_spike_setup_ex.argtypes = [i64, C.c_int, C.c_int, dptr, i64, C.c_double, i64]
+    L.orc_spike_setup_ex.restype = C.c_void_p
     L.orc_spike_free.argtypes = [C.c_void_p]
     L.orc_spike_apply.argtypes = [C.c_void_p, C.c_int, dptr, dptr]
     L.orc_spike_nboost.argtypes = [C.c_void_p]
@@ -102,12 +104,17 @@ def partition(N, P):
 class Spike:
     """Truncated-SPIKE preconditioner, CPU restatement (variant 0 = decoupled, 1 = coupled)."""
 
-    def __init__(self, band, P, boost_rel=1e-10, L=None):
+    def __init__(self, band, P, boost_rel=1e-10, L=None, tip_rows=0):
+        """tip_rows > 0: bench.py's cpu_baseline only (spike tips from solves on tip_rows rows next to the interfaces,
+        so that setup takes seconds at N = 4M); every test uses the plain setup (tip_rows = 0)."""
         self.L = L or lib()
         band = np.ascontiguousarray(band, dtype=np.float64)
         nd, N = band.shape
         self.N, self.K, self.P = N, (nd - 1) // 2, P
-        self.h = self.L.orc_spike_setup(N, self.K, P, _p(band), N, boost_rel)
+        if tip_rows:
+            self.h = self.L.orc_spike_setup_ex(N, self.K, P, _p(band), N, boost_rel, int(tip_rows))
+        else:
+            self.h = self.L.orc_spike_setup(N, self.K, P, _p(band), N, boost_rel)
         if not self.h:
             raise ValueError("orc_spike_setup failed (partition shorter than K?)")
 

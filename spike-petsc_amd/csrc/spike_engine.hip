@@ -96,6 +96,9 @@ struct spike_handle_s {
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
     double spike_tol = 1e-16;   // relative magnitude below which spike rows are dropped (fp64 rounding level)
     hipStream_t stream = nullptr;
+    int overlap = 1;            // multi-rank apply: boundary chains + exchange on a second stream beside the interior sweeps
+    hipStream_t stream2 = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     std::string err;
     // communicator
     int nranks = 1, rank = 0;
@@ -196,22 +199,26 @@ static hipError_t dalloc(T **p, size_t count)
 static inline bool exchanging(const spike_handle_s *h) { return h->nranks > 1 || h->comm != nullptr; }
 
 // ---- collectives: RCCL, or the loopback transport -------------------------------------------------
-static int coll_allgather(spike_handle h, const double *send, double *recv, size_t count)
+static int coll_allgather(spike_handle h, const double *send, double *recv, size_t count, hipStream_t st)
 {
     if (!exchanging(h)) return SPIKE_OK;
     if (h->lcomm) {
         LocalComm &c = *h->lcomm;
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(st));
         c.send[h->rank] = send;
         c.barrier();
         for (int r = 0; r < c.n; ++r)
-            HIPCHK(hipMemcpyAsync(recv + (size_t)r * count, c.send[r], sizeof(double) * count, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpyAsync(recv + (size_t)r * count, c.send[r], sizeof(double) * count, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
         c.barrier();
         return SPIKE_OK;
     }
-    NCCLCHK(g_rccl.AllGather(send, recv, count, NCCL_FLOAT64, h->comm, h->stream));
+    NCCLCHK(g_rccl.AllGather(send, recv, count, NCCL_FLOAT64, h->comm, st));
     return SPIKE_OK;
+}
+static int coll_allgather(spike_handle h, const double *send, double *recv, size_t count)
+{
+    return coll_allgather(h, send, recv, count, h->stream);
 }
 
 static int coll_allreduce(spike_handle h, double *buf, size_t count, int op)
@@ -312,6 +319,9 @@ extern "C" int spike_destroy(spike_handle h)
     spike_clear_operator(h);
     if (h->comm && g_rccl.ok()) g_rccl.CommDestroy(h->comm);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     for (int i = 0; i < 2; ++i) if (h->evDots[i]) (void)hipEventDestroy(h->evDots[i]);
     delete h;
     return SPIKE_OK;
@@ -335,6 +345,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "subsplit") h->subsplit = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
+    else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
         if (v == "refine_never" || v == "never") h->cgs_refine = 0;
         else if (v == "refine_ifneeded" || v == "ifneeded") h->cgs_refine = 1;
@@ -396,20 +407,34 @@ static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_
                       const double *scale_norm2_dev = nullptr);
 
 // ---- partitioning ------------------------------------------------------------------------------------
-static int auto_partitions(const SweepCfg &cfg, int K, int64_t n)
+// compute units of the current device (256 on MI355X); the host-only entry point spike_auto_partitions has no device
+// to ask and assumes the MI355X count
+static int device_cus()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        return cus;
+    (void)hipGetLastError();
+    return 256;
+}
+
+static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 256)
 {
     const int64_t nblk = (n + BLK - 1) / BLK;
     // Spikes of diagonally dominant systems die out over ~10-16 K rows.  A chain of 32 K rows keeps the stored part of
     // its two spikes below about half of the chain, so the coupled variant stays a ONE-pass apply (BASELINE config 2,
     // N = 1M, K = 32: 1024 chains of 1024 rows 0.179 ms in one pass, 2048 chains of 512 rows 0.233 ms in two).
     int64_t minrows = (int64_t)32 * K;
+    // K in (16, 32] (two chains per wave): measured on BASELINE config 2 (N = 1M, K = 32, round 2 sweeps): 256 chains
+    // 0.172-0.181 ms per apply (half the CUs idle), 512 chains 0.138, 1024 chains 0.162 (twice the spike traffic)
+    if (cfg.R == 32) minrows = (int64_t)64 * K;
     if (minrows < 512) minrows = 512;
     // Workgroups in whole multiples of the CU count (balance), at least 4 waves per CU (two tiles in flight per wave
     // already cover the memory latency).  Every interface costs spike and interface traffic, so FEWER chains is
     // better as long as the sweeps stay at full bandwidth -- measured at N = 4M (ms per coupled apply, half / this many
     // chains / twice): K=16 -/0.314/0.372, K=32 -/0.516/0.626, K=64 -/0.896/0.927, K=96 1.359/1.294/-,
     // K=128 2.280/1.496/1.646, K=192 3.210/2.413/-, K=256 3.975/3.069/-.
-    const int64_t ncu = 256;
+    const int64_t ncu = ncu_dev;
     int64_t target = ncu * ((4 + cfg.NW - 1) / cfg.NW) * cfg.CPW();
     if (cfg.scan) target = 8192;  // one light wave per chain: 32 waves per CU keep enough loads in flight
     int64_t byrows = n / minrows;
@@ -427,6 +452,34 @@ extern "C" int spike_auto_partitions(int K, int64_t n_local)
     return auto_partitions(cfg, K, n_local);
 }
 
+// How many chains a caller-chosen partition is cut into.  Two aims: (i) enough workgroups to fill the device, and
+// (ii) a workgroup count that deals out evenly over the CUs -- with 1.5 workgroups per CU half the CUs carry twice the
+// bytes of the others and the launch takes as long as they do (measured at N = 4M, K = 128: 256 chains 1.44 ms,
+// 384 chains 1.66 ms, 640 chains 1.71 ms per apply).  Among the S that keep a chain >= its minimum length the one with
+// the best balance wins; ties go to the SMALLER S (every cut costs spike and interface traffic).
+static int pick_subsplit(const SweepCfg &cfg, int K, int64_t n, int P_user, int ncu)
+{
+    int want = auto_partitions(cfg, K, n, ncu);   // chains that fill the device at full sweep bandwidth
+    if (const char *e = getenv("SPIKE_CHAINS_TARGET")) { const int t = atoi(e); if (t > 0) want = t; }   // measurement knob
+    const int64_t nblk = (n + BLK - 1) / BLK;
+    const int CPW = cfg.CPW();
+    int Smax = want / P_user;
+    if ((int64_t)P_user * Smax < want && (int64_t)P_user * (Smax + 1) <= 2 * (int64_t)want) ++Smax;   // P does not divide: allow one more
+    while (Smax > 1 && nblk / ((int64_t)P_user * Smax) < 1) --Smax;
+    if (Smax <= 1) return 1;
+    int best = 1;
+    double best_eff = -1.0;
+    for (int S = 1; S <= Smax; ++S) {   // upward, replaced only by a strictly better S: ties go to the smaller one
+        const int64_t wg = ((int64_t)P_user * S + CPW - 1) / CPW;
+        const int64_t rounds = (wg + ncu - 1) / ncu;
+        double eff = (double)wg / (double)(rounds * ncu);           // share of CU-slots that carry a chain
+        const double wantwg = (double)((want + CPW - 1) / CPW);
+        if ((double)wg < wantwg) eff *= (double)wg / wantwg;        // fewer workgroups than the device wants
+        if (eff > best_eff + 1e-12) { best_eff = eff; best = S; }
+    }
+    return best;
+}
+
 static int build_chains(spike_handle h)
 {
     const int64_t n = h->n;
@@ -437,12 +490,31 @@ static int build_chains(spike_handle h)
     const int64_t nblk = (n + BLK - 1) / BLK;
     if (nblk < PU) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", PU, PU, (long long)nblk);
     h->chains.resize(P);
+    // Overlapped exchange (apply_dev): the rank's first and last chain feed the all-gather, so they are made SHORTER
+    // (3/4 of an interior chain) and finish their sweeps while the interior chains still run -- where the library is
+    // free to place the cut: automatic partitioning, or a cut INSIDE a caller partition (S > 1).  A caller-chosen
+    // partition boundary is never moved (the preconditioner is P-defined).
+    const bool shorten = exchanging(h) && h->overlap && h->K > 0 && (h->opt_partitions == 0 || S > 1) && P >= 4 * CPW &&
+                         nblk >= 8 * (int64_t)P;
+    const bool short_first = shorten && h->rank > 0, short_last = shorten && h->rank < h->nranks - 1;
+    // weights in quarters: chains of the boundary workgroups 3 (narrow bands: a workgroup sweeps CPW chains in lock-step,
+    // so the whole first / last group is shortened), interior chains 4
+    const int lastgrp0 = ((P + CPW - 1) / CPW - 1) * CPW;
+    auto weight = [&](int p) -> int64_t { return ((p < CPW && short_first) || (p >= lastgrp0 && short_last)) ? 3 : 4; };
     for (int pu = 0; pu < PU; ++pu) {
-        // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range evenly
-        const int64_t b0 = (nblk * (int64_t)pu) / PU, b1 = (nblk * (int64_t)(pu + 1)) / PU;
-        for (int sidx = 0; sidx < S; ++sidx) {
-            const int p = pu * S + sidx;
-            int64_t r0 = (b0 + ((b1 - b0) * sidx) / S) * BLK, r1 = (b0 + ((b1 - b0) * (sidx + 1)) / S) * BLK;
+        // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range by weight (evenly
+        // unless a boundary chain is shortened).  Automatic partitioning: ONE range [0, nblk) split into P chains.
+        const bool flat = h->opt_partitions == 0;
+        const int64_t b0 = flat ? 0 : (nblk * (int64_t)pu) / PU, b1 = flat ? nblk : (nblk * (int64_t)(pu + 1)) / PU;
+        const int first = flat ? 0 : pu * S, cnt = flat ? P : S;
+        int64_t wtot = 0;
+        for (int q = 0; q < cnt; ++q) wtot += weight(first + q);
+        int64_t wacc = 0;
+        for (int sidx = 0; sidx < cnt; ++sidx) {
+            const int p = first + sidx;
+            const int64_t w0 = wacc, w1 = wacc + weight(p);
+            wacc = w1;
+            int64_t r0 = (b0 + ((b1 - b0) * w0) / wtot) * BLK, r1 = (b0 + ((b1 - b0) * w1) / wtot) * BLK;
             if (r1 > n || p == P - 1) r1 = n;
             if (r0 > n) r0 = n;
             const int64_t rows = r1 - r0;
@@ -451,6 +523,7 @@ static int build_chains(spike_handle h)
             h->chains[p].nrows = (int32_t)rows;
             h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
         }
+        if (flat) break;
     }
     const int ng = (P + CPW - 1) / CPW;
     h->groups.resize(ng);
@@ -471,21 +544,49 @@ static int build_chains(spike_handle h)
     return SPIKE_OK;
 }
 
+// Shape of the PCApply sweeps (SweepCfg::sDPW/sNW/sPF): how the streamed diagonals of a chain are dealt to waves and
+// how many bundles each wave keeps in flight, by how many workgroups the device gets per CU.
+static void pick_sweep_shape(spike_handle h, int ncu)
+{
+    SweepCfg &c = h->cfg;
+    c.sDPW = c.sNW = c.sPF = 0;
+    if (c.scan) return;
+    if (const char *e = getenv("SPIKE_SWEEP_SHAPE")) {   // measurement knob: "dpw,nw,pf"
+        int d = 0, w = 0, f = 0;
+        if (sscanf(e, "%d,%d,%d", &d, &w, &f) == 3 && sweep_shape_exists(c, d, w, f)) { c.sDPW = d; c.sNW = w; c.sPF = f; }
+        return;
+    }
+    (void)ncu;
+    // two waves per chain (32 < K <= 64): four bundles in flight per wave instead of two (the workgroup is small, the
+    // registers are there): 1.46 -> 1.38 ms per pass at N = 8M, K = 64
+    if (c.R == 64 && c.NW == 2 && sweep_shape_exists(c, 32, 2, 4)) { c.sDPW = 32; c.sNW = 2; c.sPF = 4; }
+}
+
 // one forward+backward pass over all chains: out = blockdiag(A_p)^{-1} (in - corrections)
 struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes are computed only where they live)
     const ChainDesc *chains = nullptr;
     const GroupDesc *groupsF = nullptr, *groupsB = nullptr;
 };
 
-static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr)
+// which units a pass covers (SweepArgs::sel*): everything, or the rank's boundary / interior chains (overlapped exchange)
+struct PassSel {
+    int sel0 = 0, stride = 1, count = 0;   // count = 0: all
+    hipStream_t st = nullptr;
+    bool use_st = false, timed = true;
+};
+
+static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr,
+                    const PassSel *sel = nullptr)
 {
     SweepArgs a;
     a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = h->P; a.K = h->K;
     a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
     a.corr_top = with_corr ? h->dCorrTop : nullptr;
     a.corr_bot = with_corr ? h->dCorrBot : nullptr;
+    if (sel) { a.sel0 = sel->sel0; a.selstride = sel->stride; a.selcount = sel->count; }
+    hipStream_t st = (sel && sel->use_st) ? sel->st : h->stream;
     const int ng = (int)h->groups.size();
-    const bool prof = h->profile != 0;
+    const bool prof = h->profile != 0 && (!sel || sel->timed);
     auto rec = [&](bool start) {
         if (!prof) return;
         if (h->nev >= (int)h->evs.size()) {
@@ -493,27 +594,27 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             h->evs.push_back({e0, e1});
         }
-        if (start) (void)hipEventRecord(h->evs[h->nev].first, h->stream);
-        else { (void)hipEventRecord(h->evs[h->nev].second, h->stream); ++h->nev; }
+        if (start) (void)hipEventRecord(h->evs[h->nev].first, st);
+        else { (void)hipEventRecord(h->evs[h->nev].second, st); ++h->nev; }
     };
     const int tag = h->ready ? 0 : 1;  // setup (spike solves) vs PCApply: distinct kernel names in a trace
     if (h->cfg.scan && h->max_chain_rows <= 64 * 64) {
         // tridiagonal chains of at most 4096 rows: both sweeps in one launch, the intermediate vector stays in registers
         a.out = out;
         rec(true);
-        HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, h->stream, tag));
+        HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, st, tag));
         rec(false);
         return SPIKE_OK;
     }
     rec(true);
-    if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, h->stream, tag));
-    else HIPCHK(launch_sweep(h->cfg, false, ng, a, h->stream, tag));
+    if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, st, tag));
+    else HIPCHK(launch_sweep(h->cfg, false, ng, a, st, tag));
     rec(false);
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
-    if (h->cfg.scan) HIPCHK(launch_scan_sweep(true, h->P, a, h->stream, tag));
-    else HIPCHK(launch_sweep(h->cfg, true, ng, a, h->stream, tag));
+    if (h->cfg.scan) HIPCHK(launch_scan_sweep(true, h->P, a, st, tag));
+    else HIPCHK(launch_sweep(h->cfg, true, ng, a, st, tag));
     rec(false);
     return SPIKE_OK;
 }
@@ -588,20 +689,34 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     };
     h->cfg = cfg;
     h->n_global = n_global; h->row0 = row0; h->n = n; h->K = K;
-    h->P_user = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n);
+    const int ncu = device_cus();
+    h->P_user = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n, ncu);
     h->S = 1;
+    int rc = SPIKE_OK;
     if (h->opt_partitions > 0 && h->subsplit && allow_subsplit && K > 0) {
         // A caller-chosen P may leave most CUs without a chain.  Cut every partition into S chains; the cuts are
         // treated like partition interfaces (truncated coupling), which reproduces the P-partition preconditioner to
         // rounding iff the spikes die inside a chain -- measured below, and undone (S = 1) when they do not.
-        const int want = auto_partitions(cfg, K, n);
-        int S = want / h->P_user;
-        const int64_t nblk = (n + BLK - 1) / BLK;
-        while (S > 1 && nblk / ((int64_t)h->P_user * S) < 1) --S;
+        int S = pick_subsplit(cfg, K, n, h->P_user, ncu);
+        if (exchanging(h)) {
+            // Ranks may own different row counts and would pick different S; the probe / redo below is collective
+            // (allreduce + a second setup), so every rank must walk the same branches: all take the smallest S.
+            double *dS = nullptr;
+            HIPCHK(tmp.alloc(&dS, 1));
+            const double neg = -(double)S;
+            HIPCHK(hipMemcpyAsync(dS, &neg, sizeof(double), hipMemcpyHostToDevice, h->stream));
+            if ((rc = coll_allreduce(h, dS, 1, NCCL_MAX))) return rc;
+            double got = 0.0;
+            HIPCHK(hipMemcpyAsync(&got, dS, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            S = (int)(-got);
+            tmp.release(dS);
+        }
         if (S > 1) h->S = S;
     }
-    int rc = build_chains(h);
+    rc = build_chains(h);
     if (rc) return rc;
+    pick_sweep_shape(h, ncu);
     const int P = h->P;
     const int nd = 2 * K + 1;
     hipStream_t st = h->stream;
@@ -688,8 +803,13 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         double *rhs = h->dTmp;
         double *sol = nullptr;
         HIPCHK(tmp.alloc(&sol, (size_t)n));
-        const bool keep_prof = h->profile;
-        h->profile = 0;
+        // the spike solves below go through run_pass: no sweep-timing events for them (restored on every exit path)
+        struct ProfileOff {
+            spike_handle hh; int keep;
+            explicit ProfileOff(spike_handle q) : hh(q), keep(q->profile) { q->profile = 0; }
+            ~ProfileOff() { hh->profile = keep; }
+        } profile_off(h);
+        const int keep_prof = profile_off.keep;
         // ---- how far do the spikes reach?  probe the first and last column of W and of V
         int m = 0;
         double *dStat = nullptr;  // [absmax_in, absmax_out, probe absmax, extent(int)]
@@ -973,18 +1093,44 @@ static int apply_dev(spike_handle h, const double *x, double *y)
 {
     hipStream_t st = h->stream;
     h->nev = 0;
-    int rc = run_pass(h, x, y, false);
-    if (rc) return rc;
+    int rc = SPIKE_OK;
     const bool coupled = h->variant == SPIKE_VARIANT_COUPLED;
     const int nif = coupled ? h->nif : h->nif_int;  // decoupled: only the cuts inside the caller's partitions
-    if (nif > 0) {
-        const bool multi = coupled && exchanging(h);
-        const int K = h->K, P = h->P;
-        if (multi) {  // [g_top(first partition) | g_bottom(last partition)] = the first and last K entries of the local vector
-            hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, y, h->n, K, h->dSend);
-            HIPCHK(hipGetLastError());
-            if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K))) return rc;
+    const bool multi = coupled && nif > 0 && exchanging(h);
+    // units the sweep launches are made of: groups of CPW chains (tile kernels) or single chains (scan kernels)
+    const int nunits = h->cfg.scan ? h->P : (int)h->groups.size();
+    if (multi && h->overlap && nunits >= 3) {
+        // The exchange needs only the top tip of the rank's FIRST chain and the bottom tip of its LAST chain.  Those two
+        // (build_chains made them shorter than the interior chains) are swept on a second stream, which then copies the
+        // tips and runs the all-gather while the interior chains still sweep on the main stream; the streams join before
+        // the interface solves.  Same kernels on the same data: the result is bit-identical to the serial order.
+        if (!h->stream2) {
+            HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
         }
+        HIPCHK(hipEventRecord(h->evFork, st));           // x (and everything before this apply) is ready on the main stream
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->evFork, 0));
+        PassSel edge, inner;
+        edge.sel0 = 0; edge.stride = nunits - 1; edge.count = 2; edge.st = h->stream2; edge.use_st = true; edge.timed = false;
+        inner.sel0 = 1; inner.stride = 1; inner.count = nunits - 2;
+        if ((rc = run_pass(h, x, y, false, nullptr, &edge))) return rc;
+        hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, h->stream2, y, h->n, h->K, h->dSend);
+        HIPCHK(hipGetLastError());
+        if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K, h->stream2))) return rc;
+        HIPCHK(hipEventRecord(h->evJoin, h->stream2));
+        if ((rc = run_pass(h, x, y, false, nullptr, &inner))) return rc;
+        HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));
+    } else {
+        if ((rc = run_pass(h, x, y, false))) return rc;
+        if (multi) {  // [g_top(first partition) | g_bottom(last partition)] = the first and last K entries of the local vector
+            hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, y, h->n, h->K, h->dSend);
+            HIPCHK(hipGetLastError());
+            if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K))) return rc;
+        }
+    }
+    if (nif > 0) {
+        const int K = h->K, P = h->P;
         if (h->spike_m > 0) {
             // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
             if (!coupled) {  // tip solutions of the caller-level interfaces must read as zero
@@ -1139,7 +1285,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
         auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
         F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
         for (int i = 0; i < 2; ++i) {
-            if (h->hostDots[i]) (void)hipHostFree(h->hostDots[i]);
+            if (h->hostDots[i]) { (void)hipHostFree(h->hostDots[i]); h->hostDots[i] = nullptr; }
             HIPCHK(hipHostMalloc((void **)&h->hostDots[i], sizeof(double) * ((size_t)m + 3), hipHostMallocDefault));
             if (!h->evDots[i]) HIPCHK(hipEventCreateWithFlags(&h->evDots[i], hipEventDisableTiming));
         }

@@ -28,6 +28,10 @@ struct SweepCfg {
     int DPW;  // diagonals per wave (= tile entries per lane per wave)
     int NW;   // waves per chain
     bool scan = false;  // K = 1: no tiles, one multiplier per row, wavefront scan (k_scan_sweep)
+    // sweep-time shape of PCApply (0 = the base shape above): the tile layout is independent of how the KP diagonals are
+    // dealt to waves, so setup may pick another (DPW, NW, prefetch depth) for the apply sweeps (launch_sweep)
+    int sDPW = 0, sNW = 0, sPF = 0;
+    int basePF() const { return R == 4 ? 12 : R == 8 ? 8 : R == 16 ? 4 : 2; }
     int KP() const { return scan ? 1 : DPW * NW; }
     int CPW() const { return 64 / R; }
     int64_t tile_doubles() const { return (int64_t)NW * DPW * 64; }
@@ -44,6 +48,10 @@ struct SweepArgs {
     const double *corr_top;  // [nchains*K] or null (forward only)
     const double *corr_bot;  // [nchains*K] or null
     int K;
+    // launch over a SUBSET of the workgroups' units (groups for k_sweep, chains for the scan kernels): unit index =
+    // sel0 + i * selstride for i in [0, selcount); selcount = 0: all.  The multi-rank apply sweeps the rank's first and
+    // last chain on a second stream (their tips feed the exchange) while the interior chains run on the main stream.
+    int sel0 = 0, selstride = 1, selcount = 0;
 };
 
 // One reduced (interface) system between partition "lo" and the partition below it.
@@ -64,6 +72,7 @@ struct IfaceDesc {
 };
 
 bool pick_cfg(int K, SweepCfg *cfg);
+bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf);
 
 // launchers (spike_kernels.hip)
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag = 0);

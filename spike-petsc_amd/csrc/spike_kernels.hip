@@ -68,7 +68,16 @@ __device__ __forceinline__ int64_t tile_elem(int DPW, int lane, int d)
 // ------------------------------------------------------------------------------------------
 // TAG only names the instantiation: 0 = the sweeps of PCApply, 1 = the spike solves of setup (sub-ranges of the chains),
 // so that a kernel trace keeps the two populations apart.
-template <int R, int DPW, int NW, bool REV, int TAG>
+//
+// Prefetch: a step's inputs -- its tile slice (NLD 16-byte loads per lane), its right-hand-side entry and (forward) its
+// 1/diag entry -- form one BUNDLE; PF bundles are in flight per wave (registers, statically named: the loop is unrolled
+// PF times).  Everything a step waits for comes from its own bundle, so the wait is "all but the (PF-1) younger
+// bundles" (vector-memory operations complete in order) and never drains the queue.  Round 1 loaded the right-hand
+// side inside the step, i.e. BEHIND the next tile's prefetch: every step then waited for a whole memory round trip and
+// a CU could not pull more than ~30 GB/s -- invisible with one chain per CU on all 256 CUs (HBM-bound), but half speed
+// with 128 chains (strong scaling, N/8 rows per GPU).  All loads of the main loop are unconditional (clamped
+// addresses): a load under a branch would make the compiler's s_waitcnt counts conservative at the join.
+template <int R, int DPW, int NW, int PF, bool REV, int TAG>
 __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
 {
     constexpr int CPW = 64 / R;
@@ -87,12 +96,13 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane / R, lr = lane % R;
-    const int p = blockIdx.x * CPW + c;
+    const int grp = a.sel0 + (int)blockIdx.x * a.selstride;
+    const int p = grp * CPW + c;
     const bool valid = p < a.nchains;
     ChainDesc cd;
     cd.row0 = 0; cd.nrows = 0; cd.nsteps = 0;
     if (valid) cd = a.chains[p];
-    const GroupDesc gd = a.groups[blockIdx.x];
+    const GroupDesc gd = a.groups[grp];
 
     for (int t = threadIdx.x; t < CPW * 2 * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
     for (int t = threadIdx.x; t < CPW * (KP + R); t += NW * 64) (&W2[0][0])[t] = 0.0;
@@ -101,25 +111,37 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     const d2 *tp = reinterpret_cast<const d2 *>(a.tiles) + gd.tile0 * TILE2 + (int64_t)(w * NLD) * 64 + lane;
     const int K = a.K;
     const double *ctop = a.corr_top, *cbot = a.corr_bot;
+    const int ns = gd.maxsteps;
+    if (ns <= 0) return;
 
-    d2 tA[NLD], tB[NLD];
+    struct Bundle { d2 t[NLD]; double fv, dv; };
+    Bundle bq[PF];
     int pos = 0;
 
-    auto load_tile = [&](d2(&t)[NLD], int s) {
-        const d2 *q = tp + (int64_t)s * TILE2;
+    // local row of this lane in step s (may lie outside the chain: padded last block, shorter chain of the group)
+    auto row_of = [&](int s) -> int { return REV ? (cd.nsteps * R - 1 - (s * R + lr)) : (s * R + lr); };
+
+    auto issue = [&](Bundle &q, int s) {
+        const int rl = row_of(s);
+        const bool act = valid && s < cd.nsteps && rl >= 0 && rl < cd.nrows;
+        const int64_t gi = cd.row0 + (act ? rl : 0);        // clamped: the load is unconditional, the value selected later
+        q.fv = a.in[gi];
+        if (!REV) q.dv = a.dinv[gi];
+        const d2 *src = tp + (int64_t)s * TILE2;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) t[i] = __builtin_nontemporal_load(q + i * 64);
+        for (int i = 0; i < NLD; ++i) q.t[i] = __builtin_nontemporal_load(src + i * 64);
     };
 
-    auto step = [&](const d2(&t)[NLD], int s) {
+    auto step = [&](const Bundle &q, int s) {
+        const d2(&t)[NLD] = q.t;
         const bool actc = valid && s < cd.nsteps;
-        const int rl = REV ? (cd.nsteps * R - 1 - (s * R + lr)) : (s * R + lr);
+        const int rl = row_of(s);
         const bool act = actc && rl < cd.nrows;
         const int64_t gi = cd.row0 + rl;
-        double fv = act ? a.in[gi] : 0.0;
+        double fv = act ? q.fv : 0.0;
         double dv = 1.0;
         if (!REV) {
-            if (act) dv = a.dinv[gi];
+            if (act) dv = q.dv;
             if (ctop != nullptr && act) {
                 if (rl < K) fv -= ctop[(int64_t)p * K + rl];
                 if (rl >= cd.nrows - K) fv -= cbot[(int64_t)p * K + (rl - (cd.nrows - K))];
@@ -134,11 +156,18 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         WAVE_LDS_FENCE();
         // pos is a multiple of R and WS a multiple of R, so (pos & (WS-1)) + WS + lr - d stays inside [R, 2*WS)
         const double *wp = &W[c][(pos & (WS - 1)) + WS + lr - KP - w * DPW];
+        // The lane's DPW window values are requested back to back and only then consumed: left to itself the compiler
+        // (short of registers next to the prefetched bundles) issues read - wait - 2 FMA - read ..., i.e. NLD serial LDS
+        // round trips of ~64 cycles each per phase, which made the block step, not HBM, the limit of a lone chain.
+        double xa[DPW];
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) xa[i] = wp[KP - 1 - i];
+        __builtin_amdgcn_sched_barrier(0);
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            acc0 = fma(t[i].x, wp[KP - 1 - 2 * i], acc0);   // d = w*DPW + 1 + 2i
-            acc1 = fma(t[i].y, wp[KP - 2 - 2 * i], acc1);   // d + 1
+            acc0 = fma(t[i].x, xa[2 * i], acc0);       // d = w*DPW + 1 + 2i
+            acc1 = fma(t[i].y, xa[2 * i + 1], acc1);   // d + 1
         }
         double acc = acc0 + acc1;
         if (NW > 1) {
@@ -154,12 +183,16 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         WAVE_LDS_FENCE();
         double g = tt;
         if (w < NWB) {
+            const double *w2p = &W2[c][KP + lr - w * DPW - 1];
+            double xb[DPW];
+#pragma unroll
+            for (int i = 0; i < DPW; ++i) xb[i] = w2p[-i];
+            __builtin_amdgcn_sched_barrier(0);
             double b0 = 0.0, b1 = 0.0;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int d0 = w * DPW + 1 + 2 * i;
-                b0 = fma(t[i].x, W2[c][KP + lr - d0], b0);
-                b1 = fma(t[i].y, W2[c][KP + lr - d0 - 1], b1);
+                b0 = fma(t[i].x, xb[2 * i], b0);       // d0 = w*DPW + 1 + 2i
+                b1 = fma(t[i].y, xb[2 * i + 1], b1);
             }
             if (NW > 1) red2[w][lane] = b0 + b1;
             else g = tt - (b0 + b1);
@@ -179,45 +212,104 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         pos += R;
     };
 
-    const int ns = gd.maxsteps;
-    if (ns > 0) load_tile(tA, 0);
-    for (int s = 0; s < ns; s += 2) {
-        if (s + 1 < ns) load_tile(tB, s + 1);
-        step(tA, s);
-        if (s + 1 < ns) {
-            if (s + 2 < ns) load_tile(tA, s + 2);
-            step(tB, s + 1);
+    // prologue: PF bundles in flight (a chain shorter than PF steps re-requests its last tile: harmless)
+#pragma unroll
+    for (int q = 0; q < PF; ++q) issue(bq[q], q < ns ? q : ns - 1);
+    int s = 0;
+    // main loop: every prefetch is in range, no load sits under a branch
+    for (; s + 2 * PF <= ns; s += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            step(bq[q], s + q);
+            issue(bq[q], s + q + PF);
+        }
+    }
+    // tail (< 2 PF steps): prefetch only what exists
+    for (; s < ns; s += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            if (s + q < ns) {
+                step(bq[q], s + q);
+                if (s + q + PF < ns) issue(bq[q], s + q + PF);
+            }
         }
     }
 }
 
-template <int R, int DPW, int NW>
+// ---- sweep shapes ------------------------------------------------------------------------------------------
+// The tile layout does not depend on how the KP streamed diagonals are dealt to waves: entry (lane, d) sits at
+// ((d-1)/2 * 64 + lane) * 2 + (d-1)%2 whatever DPW is.  So the SAME packed factors can be swept by NW = KP/DPW waves
+// for any DPW that divides KP, chosen at launch time:
+//   * few chains (fewer workgroups than ~2 per CU): more, lighter waves per chain -- 8 waves x 16 diagonals instead of
+//     4 x 32 at K = 128 -- put twice the loads in flight per CU with half the registers per bundle, and two waves per
+//     SIMD hide each other's LDS round trips;
+//   * many chains: the heavy shape (fewer barriers' worth of waves per byte).
+// Prefetch depth PF: (PF - 1) bundles of NLD + 2 loads must stay below the 6-bit vmcnt range (63), and the bundles live
+// in registers (NLD*4 + 4 VGPRs each).
+template <int R, int DPW, int NW, int PF>
 static hipError_t launch_sweep_t(bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag)
 {
     const dim3 g(ngroups), b(NW * 64);
     if (tag == 0) {
-        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true, 0>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false, 0>), g, b, 0, st, a);
+        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, true, 0>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, false, 0>), g, b, 0, st, a);
     } else {
-        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, true, 1>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, false, 1>), g, b, 0, st, a);
+        if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, true, 1>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, false, 1>), g, b, 0, st, a);
     }
     return hipGetLastError();
 }
 
+// same, PCApply only (TAG 0): the alternative shapes are not used by setup's spike solves
+template <int R, int DPW, int NW, int PF>
+static hipError_t launch_sweep_a(bool rev, int ngroups, const SweepArgs &a, hipStream_t st)
+{
+    const dim3 g(ngroups), b(NW * 64);
+    if (rev) hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, true, 0>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_sweep<R, DPW, NW, PF, false, 0>), g, b, 0, st, a);
+    return hipGetLastError();
+}
+
+// shape list (R, DPW, NW, PF) beyond the base shapes; X(R, DPW, NW, PF)
+#define SPIKE_ALT_SHAPES(X)                                                                          \
+    X(32, 8, 4, 4) X(32, 16, 2, 3)                                                                   \
+    X(64, 32, 2, 4) X(64, 32, 3, 4) X(64, 32, 4, 4)                                                  \
+    X(64, 16, 4, 2) X(64, 16, 4, 4) X(64, 16, 6, 2) X(64, 16, 6, 4) X(64, 16, 8, 2) X(64, 16, 8, 4)  \
+    X(64, 16, 12, 2) X(64, 16, 12, 3) X(64, 16, 16, 2) X(64, 16, 16, 3)
+
+bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf)
+{
+    if (dpw * nw != cfg.DPW * cfg.NW) return false;
+    if (dpw == cfg.DPW && nw == cfg.NW && pf == cfg.basePF()) return true;
+#define X(R_, D_, N_, P_) if (cfg.R == R_ && dpw == D_ && nw == N_ && pf == P_) return true;
+    SPIKE_ALT_SHAPES(X)
+#undef X
+    return false;
+}
+
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag)
 {
+    if (a.selcount > 0) ngroups = a.selcount;
     if (ngroups <= 0) return hipSuccess;
-    if (cfg.R == 4) return launch_sweep_t<4, 4, 1>(rev, ngroups, a, st, tag);
-    if (cfg.R == 8) return launch_sweep_t<8, 8, 1>(rev, ngroups, a, st, tag);
-    if (cfg.R == 16) return launch_sweep_t<16, 16, 1>(rev, ngroups, a, st, tag);
-    if (cfg.R == 32) return launch_sweep_t<32, 32, 1>(rev, ngroups, a, st, tag);
+    const int dpw = (tag == 0 && cfg.sDPW > 0) ? cfg.sDPW : cfg.DPW, nw = (tag == 0 && cfg.sNW > 0) ? cfg.sNW : cfg.NW;
+    const int pf = (tag == 0 && cfg.sPF > 0) ? cfg.sPF : cfg.basePF();
+    if (!(dpw == cfg.DPW && nw == cfg.NW && pf == cfg.basePF())) {
+#define X(R_, D_, N_, P_) if (cfg.R == R_ && dpw == D_ && nw == N_ && pf == P_) return launch_sweep_a<R_, D_, N_, P_>(rev, ngroups, a, st);
+        SPIKE_ALT_SHAPES(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
+    // base shapes (what pick_cfg gives; PF = SweepCfg::basePF)
+    if (cfg.R == 4) return launch_sweep_t<4, 4, 1, 12>(rev, ngroups, a, st, tag);
+    if (cfg.R == 8) return launch_sweep_t<8, 8, 1, 8>(rev, ngroups, a, st, tag);
+    if (cfg.R == 16) return launch_sweep_t<16, 16, 1, 4>(rev, ngroups, a, st, tag);
+    if (cfg.R == 32) return launch_sweep_t<32, 32, 1, 2>(rev, ngroups, a, st, tag);
     switch (cfg.NW) {
-    case 2: return launch_sweep_t<64, 32, 2>(rev, ngroups, a, st, tag);
-    case 3: return launch_sweep_t<64, 32, 3>(rev, ngroups, a, st, tag);
-    case 4: return launch_sweep_t<64, 32, 4>(rev, ngroups, a, st, tag);
-    case 6: return launch_sweep_t<64, 32, 6>(rev, ngroups, a, st, tag);
-    case 8: return launch_sweep_t<64, 32, 8>(rev, ngroups, a, st, tag);
+    case 2: return launch_sweep_t<64, 32, 2, 2>(rev, ngroups, a, st, tag);
+    case 3: return launch_sweep_t<64, 32, 3, 2>(rev, ngroups, a, st, tag);
+    case 4: return launch_sweep_t<64, 32, 4, 2>(rev, ngroups, a, st, tag);
+    case 6: return launch_sweep_t<64, 32, 6, 2>(rev, ngroups, a, st, tag);
+    case 8: return launch_sweep_t<64, 32, 8, 2>(rev, ngroups, a, st, tag);
     }
     return hipErrorInvalidValue;
 }
@@ -418,8 +510,9 @@ __global__ __launch_bounds__(256) void k_scan_sweep(SweepArgs s)
 {
     constexpr int U = 8;  // segments per iteration
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= s.nchains) return;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (s.selcount > 0 ? s.selcount : s.nchains)) return;
+    const int p = s.sel0 + unit * s.selstride;
     const ChainDesc cd = s.chains[p];
     const double *coef = s.tiles;
     const int nseg = (cd.nrows + 63) / 64;
@@ -466,8 +559,9 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 {
     constexpr int U = 8;
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= s.nchains) return;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (s.selcount > 0 ? s.selcount : s.nchains)) return;
+    const int p = s.sel0 + unit * s.selstride;
     const ChainDesc cd = s.chains[p];
     const double *lcoef = s.tiles;
     const int nseg = (cd.nrows + 63) / 64;   // host guarantees nseg <= MAXSEG
@@ -530,6 +624,7 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 // forward + backward in one launch when every chain fits the register-resident form (max_rows <= 64 segments)
 hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, const double *cu, hipStream_t st, int tag)
 {
+    if (a.selcount > 0) nchains = a.selcount;
     if (nchains <= 0) return hipSuccess;
     const dim3 g((nchains + 3) / 4), b(256);
     if (max_rows <= 32 * 64) {
@@ -544,6 +639,7 @@ hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, cons
 
 hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag)
 {
+    if (a.selcount > 0) nchains = a.selcount;
     if (nchains <= 0) return hipSuccess;
     const dim3 g((nchains + 3) / 4), b(256);
     if (tag == 0) {

@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hostbox: host-only oracle comparison (MC64, AWBM, known answers) that must ALSO be "
+                                       "in the GPU box's record: runs under -m 'not gpu' here and is added to -m gpu there")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` is the driver's recorded run on the MI355X box.  The host-side oracle comparisons need no GPU, but a
+    record that lacks them says nothing about a-8/a-9/f-2 parity, so under `-m gpu` they carry the gpu marker too."""
+    if (config.getoption("markexpr") or "").strip() == "gpu":
+        for it in items:
+            if it.get_closest_marker("hostbox") is not None:
+                it.add_marker(pytest.mark.gpu)
 
 
 @pytest.fixture(scope="session")

@@ -69,5 +69,5 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(32, N) == 2048          # 2 chains per wave, 1024 one-wave workgroups
     assert L.spike_auto_partitions(1, 2 ** 24) == 8192     # scan path
     assert L.spike_auto_partitions(128, 32768) == 8        # small systems: a partition keeps >= 32 K rows
-    assert L.spike_auto_partitions(32, 2 ** 20) == 1024    # BASELINE config 2: chains long enough for the one-pass form
+    assert L.spike_auto_partitions(32, 2 ** 20) == 512     # BASELINE config 2: a chain keeps >= 64 K rows (measured: 512 chains 0.138 ms, 1024 0.162)
     assert L.spike_auto_partitions(300, N) < 0             # K > 256 is refused

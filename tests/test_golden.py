@@ -9,6 +9,7 @@ import pytest
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.mark.hostbox
 def test_mc64_reference_known_answer_fixture():
     from conftest import _ensure_built
     _ensure_built()

@@ -35,6 +35,7 @@ def test_host_symbols_exported(H):
     assert not missing, missing
 
 
+@pytest.mark.hostbox
 def test_mc64_known_answer_wbm_3x3(H):
     # rows of the matrix at src/wbm.c:485-497: r0={(1,8),(2,3)}, r1={(1,2),(2,1)}, r2={(0,4)}; the wrapper hands the
     # CSR arrays to the CSC interface (src/petsc_mat_wbm.c:29,52)
@@ -108,6 +109,7 @@ def test_mc64_dense_column_rule_and_singular(H):
     assert num == 3 and (perm < 0).sum() == 1 and sorted(np.where(perm < 0, -perm - 1, perm)) == [0, 1, 2, 3]
 
 
+@pytest.mark.hostbox
 def test_wbm_ordering_conventions(H):
     L = H.lib()
     H.chk(L.SpikePetscRegisterAll())
@@ -193,6 +195,7 @@ def test_fiedler_small_exact_and_components(H):
     assert sorted(o[:5]) == [0, 1, 2, 3, 4] and sorted(o[5:8]) == [5, 6, 7] and o[8] == 8
 
 
+@pytest.mark.hostbox
 def test_matcreatesubmatrixbanded_is_reference_rule(H, ):
     import ctypes as C
     import oracle as O
@@ -264,6 +267,7 @@ def _awbm_py(n, ia, ja, a):
     return np.array(p)
 
 
+@pytest.mark.hostbox
 def test_awbm_matches_independent_restatement(H):
     for seed, n in [(0, 40), (1, 150), (2, 400)]:
         A = circuit_like(n, seed=seed).tocsr()

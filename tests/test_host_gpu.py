@@ -116,6 +116,14 @@ def test_config4_pipeline_mc64_fiedler_band_gmres(H, oracle):
     H.chk(L.KSPReorderGetOrdering(ksp, C.byref(r), C.byref(c)))
     perm, *_ = H.mc64_job5(n, A.indptr, A.indices, A.data)
     assert np.array_equal(H.is_indices(r), perm) and np.array_equal(H.is_indices(c), np.arange(n))
+    # ... and that kernel is pinned to the ORACLE (oracle/mc64_oracle.py, written separately from the reference text),
+    # bit for bit, on a tie-heavy matrix of the same family small enough for the pure-Python oracle
+    from oracle import mc64_oracle as MO
+    As = sp.csc_matrix(circuit_like(1500, seed=11))
+    As.sort_indices()
+    pp, pu, pv, pnum = H.mc64_job5(1500, As.indptr, As.indices, As.data)
+    po, uo, vo, no = MO.mc64_job5(1500, As.indptr, As.indices, As.data)
+    assert pnum == no and np.array_equal(pp, np.array(po)) and np.array_equal(pu, np.array(uo)) and np.array_equal(pv, np.array(vo))
     H.chk(L.KSPDestroy(C.byref(ksp)))
     # without the reorderings the same banded PC is useless (band holds almost nothing of A)
     err2, its2, reason2, ksp2, _ = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=60, pc_type="none")

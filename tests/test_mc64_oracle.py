@@ -15,6 +15,8 @@ from oracle import mc64_oracle as MO
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+pytestmark = pytest.mark.hostbox   # runs in BOTH suites (tests/conftest.py)
+
 
 @pytest.fixture(scope="module")
 def H():

@@ -66,6 +66,61 @@ def test_sharded_apply_equals_single_and_oracle(spike, oracle, G, N, K, Pl, vari
     assert np.linalg.norm(x - single) <= 1e-12 * np.linalg.norm(single)
 
 
+@pytest.mark.parametrize("delta", [1.2, 0.8])
+def test_unequal_row_blocks_take_the_same_collective_branches(spike, oracle, delta):
+    """Ranks that own different row counts (4032 vs 4096 rows) would pick different sub-split factors on their own; the
+    sub-split decision, its probe and the redo (delta = 0.8: the spikes do not die inside a chain) are collective, so
+    every rank must walk the same branches (mismatched collectives).  Result = the 8-partition oracle."""
+    import torch
+    G, N, K, Pl = 2, 8128, 16, 4
+    band = oracle.gen_band(N, K, delta=delta)
+    f = oracle.gen_vec(N)
+    cuts = _split(N, G)
+    assert cuts[1] - cuts[0] != cuts[2] - cuts[1]
+
+    def fn(r, sp):
+        sp.set_option("partitions", Pl)
+        r0, r1 = cuts[r], cuts[r + 1]
+        sp.setup_band(np.ascontiguousarray(band[:, r0:r1]), n_global=N, row0=r0)
+        x = sp.apply(torch.from_numpy(f[r0:r1].copy()).cuda())
+        torch.cuda.synchronize()
+        return x.cpu().numpy(), sp.info().chains_local
+
+    res = _run_ranks(spike, G, fn)
+    x = np.concatenate([r[0] for r in res])
+    assert res[0][1] == res[1][1]                      # the same number of chains per partition on both ranks
+    ref = oracle.Spike(band, G * Pl).apply(f, 1)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("G,N,K", [(2, 65536, 16), (3, 98304, 40), (2, 131072, 128), (2, 32768, 1), (2, 65536, 4)])
+def test_overlapped_exchange_is_bit_identical_and_exact(spike, oracle, G, N, K):
+    """Automatic partitioning on several ranks: the rank-boundary chains are shortened and swept on a second stream
+    with the all-gather behind them while the interior chains run (boundary first, exchange overlapped).
+    Same kernels on the same data in another launch order: bit-identical to the serial order; and on this dominant
+    system truncated SPIKE equals the exact band solve."""
+    import torch
+    band = oracle.gen_band(N, K, delta=1.2)
+    f = oracle.gen_vec(N)
+    cuts = _split(N, G)
+    def fn(r, sp):
+        r0, r1 = cuts[r], cuts[r + 1]
+        sp.setup_band(np.ascontiguousarray(band[:, r0:r1]), n_global=N, row0=r0)   # overlap_exchange is on by default
+        fr = torch.from_numpy(f[r0:r1].copy()).cuda()
+        xs = [sp.apply(fr) for _ in range(3)]                  # repeated: the second stream and its events are reused
+        sp.set_option("overlap_exchange", "off")               # same chains, serial launch order
+        xo = sp.apply(fr)
+        torch.cuda.synchronize()
+        assert all(torch.equal(xs[0], q) for q in xs[1:]) and torch.equal(xs[0], xo)
+        return xs[0].cpu().numpy(), sp.info().chains_local
+
+    res = _run_ranks(spike, G, fn)
+    out = {"on": np.concatenate([r[0] for r in res])}
+    assert all(r[1] >= 3 for r in res)
+    exact = oracle.Spike(band, 1).apply(f, 0)
+    assert np.linalg.norm(out["on"] - exact) <= 1e-10 * np.linalg.norm(exact)
+
+
 def test_sharded_gmres_and_matvec(spike, oracle):
     import torch
     G, N, K, Pl = 2, 32768, 32, 8

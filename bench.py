@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ksp", action="store_true")
     ap.add_argument("--no-extra-scaling", action="store_true", help="N > 1: skip the second (other-scaling) measurement")
+    ap.add_argument("--rccl-selftest", default=None, choices=["overlap", "serial"],
+                    help="one GPU: join a REAL one-rank RCCL communicator (SPIKE_RCCL_SELFTEST=1) so that the exchange step of the "
+                         "multi-rank apply (tip copy + ncclAllGather, overlapped with the interior sweeps or serial) runs and is timed")
     ap.add_argument("--ksp-iters", type=int, default=30)
     ap.add_argument("--ksp-delta", type=float, default=1.0,
                     help="KSP operator: same off-diagonals, this diagonal dominance (the PC is built with --delta); 0 = skip")
@@ -168,6 +171,8 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     torch.cuda.set_device(local_rank)
+    if os.environ.get("SPIKE_BENCH_SIDE_STREAM"):   # measurement knob: run on a non-default stream
+        torch.cuda.set_stream(torch.cuda.Stream())
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -194,7 +199,11 @@ def main():
         r0 = (nblk * rank // world) * 64
         r1 = N if rank == world - 1 else (nblk * (rank + 1) // world) * 64
         n_local = r1 - r0
-        sp = S.Spike(partitions=args.partitions, variant=args.variant, profile=True)
+        sp = S.Spike(partitions=args.partitions, variant=args.variant, profile=False)
+        if world == 1 and args.rccl_selftest:
+            os.environ["SPIKE_RCCL_SELFTEST"] = "1"
+            sp.comm_init(1, 0, S.unique_id())
+            sp.set_option("overlap_exchange", "on" if args.rccl_selftest == "overlap" else "off")
         if world > 1:
             uid = torch.zeros(S.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -224,8 +233,17 @@ def main():
             sp.apply(b, x)
         barrier()
         dt = allmax(time.perf_counter() - t0)
-        # kernel time of the LAST apply from HIP events recorded on the handle's stream
-        sweep_ms, sweep_launches = sp.last_sweep_ms()
+        # device time of the dominant kernel (the forward + backward sweep launches): HIP events recorded by the library
+        # on the stream it launches on, around each sweep launch -- in a few EXTRA applies outside the timed region (the
+        # event records themselves cost ~5 us per launch, which would distort the timed loop at the small sizes)
+        sp.set_option("profile", 1)
+        samples = []
+        for _ in range(5):
+            sp.apply(b, x)
+            samples.append(sp.last_sweep_ms())
+        sp.set_option("profile", 0)
+        samples.sort()
+        sweep_ms, sweep_launches = samples[len(samples) // 2]
         err = allmax(float((x - u).abs().max()))
         p = int(info.passes)          # 1: decoupled, or coupled with stored spikes; 2: coupled re-solving
         res = {"N": N, "n_local": n_local, "info": info, "P_total": P_total, "setup_s": setup_s, "dt": dt, "err": err, "passes": p,
@@ -254,7 +272,6 @@ def main():
             # Left-preconditioned GMRES(30), fixed iteration count (rtol = 0 so it never stops early).  The reported figure
             # is on an operator the preconditioner does NOT invert exactly -- the usual case (PC from a nearby or lagged
             # matrix): A' = the same off-diagonals with diagonal dominance --ksp-delta, PC built with --delta.
-            sp.set_option("profile", 0)
             xg = torch.zeros_like(b)
             sp.gmres(b, xg, restart=30, rtol=0.0, maxit=3)  # warm-up (allocates the Krylov basis)
             ksp = {}

@@ -96,7 +96,7 @@ struct spike_handle_s {
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
     double spike_tol = 1e-16;   // relative magnitude below which spike rows are dropped (fp64 rounding level)
     hipStream_t stream = nullptr;
-    int overlap = 1;            // multi-rank apply: boundary chains + exchange on a second stream beside the interior sweeps
+    int overlap = 1;            // multi-rank apply: exchange + rank-boundary interfaces on a second stream beside the local coupling work
     hipStream_t stream2 = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     std::string err;
@@ -114,6 +114,7 @@ struct spike_handle_s {
     std::vector<GroupDesc> groups;
     int64_t ntiles = 0, maxsteps = 0;
     int max_chain_rows = 0;     // longest chain (the fused tridiagonal solve keeps a whole chain in registers)
+    int min_chain_rows = 0;
     size_t factor_doubles = 0;  // doubles of packed L factors (= of packed U factors) one sweep streams
     int nif = 0;
     // device buffers
@@ -490,31 +491,12 @@ static int build_chains(spike_handle h)
     const int64_t nblk = (n + BLK - 1) / BLK;
     if (nblk < PU) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", PU, PU, (long long)nblk);
     h->chains.resize(P);
-    // Overlapped exchange (apply_dev): the rank's first and last chain feed the all-gather, so they are made SHORTER
-    // (3/4 of an interior chain) and finish their sweeps while the interior chains still run -- where the library is
-    // free to place the cut: automatic partitioning, or a cut INSIDE a caller partition (S > 1).  A caller-chosen
-    // partition boundary is never moved (the preconditioner is P-defined).
-    const bool shorten = exchanging(h) && h->overlap && h->K > 0 && (h->opt_partitions == 0 || S > 1) && P >= 4 * CPW &&
-                         nblk >= 8 * (int64_t)P;
-    const bool short_first = shorten && h->rank > 0, short_last = shorten && h->rank < h->nranks - 1;
-    // weights in quarters: chains of the boundary workgroups 3 (narrow bands: a workgroup sweeps CPW chains in lock-step,
-    // so the whole first / last group is shortened), interior chains 4
-    const int lastgrp0 = ((P + CPW - 1) / CPW - 1) * CPW;
-    auto weight = [&](int p) -> int64_t { return ((p < CPW && short_first) || (p >= lastgrp0 && short_last)) ? 3 : 4; };
     for (int pu = 0; pu < PU; ++pu) {
-        // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range by weight (evenly
-        // unless a boundary chain is shortened).  Automatic partitioning: ONE range [0, nblk) split into P chains.
-        const bool flat = h->opt_partitions == 0;
-        const int64_t b0 = flat ? 0 : (nblk * (int64_t)pu) / PU, b1 = flat ? nblk : (nblk * (int64_t)(pu + 1)) / PU;
-        const int first = flat ? 0 : pu * S, cnt = flat ? P : S;
-        int64_t wtot = 0;
-        for (int q = 0; q < cnt; ++q) wtot += weight(first + q);
-        int64_t wacc = 0;
-        for (int sidx = 0; sidx < cnt; ++sidx) {
-            const int p = first + sidx;
-            const int64_t w0 = wacc, w1 = wacc + weight(p);
-            wacc = w1;
-            int64_t r0 = (b0 + ((b1 - b0) * w0) / wtot) * BLK, r1 = (b0 + ((b1 - b0) * w1) / wtot) * BLK;
+        // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range evenly
+        const int64_t b0 = (nblk * (int64_t)pu) / PU, b1 = (nblk * (int64_t)(pu + 1)) / PU;
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const int p = pu * S + sidx;
+            int64_t r0 = (b0 + ((b1 - b0) * sidx) / S) * BLK, r1 = (b0 + ((b1 - b0) * (sidx + 1)) / S) * BLK;
             if (r1 > n || p == P - 1) r1 = n;
             if (r0 > n) r0 = n;
             const int64_t rows = r1 - r0;
@@ -523,7 +505,6 @@ static int build_chains(spike_handle h)
             h->chains[p].nrows = (int32_t)rows;
             h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
         }
-        if (flat) break;
     }
     const int ng = (P + CPW - 1) / CPW;
     h->groups.resize(ng);
@@ -540,7 +521,11 @@ static int build_chains(spike_handle h)
     h->ntiles = t0;
     h->maxsteps = ms;
     h->max_chain_rows = 0;
-    for (int p = 0; p < P; ++p) h->max_chain_rows = std::max<int>(h->max_chain_rows, h->chains[p].nrows);
+    h->min_chain_rows = h->chains[0].nrows;
+    for (int p = 0; p < P; ++p) {
+        h->max_chain_rows = std::max<int>(h->max_chain_rows, h->chains[p].nrows);
+        h->min_chain_rows = std::min<int>(h->min_chain_rows, h->chains[p].nrows);
+    }
     return SPIKE_OK;
 }
 
@@ -568,25 +553,16 @@ struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes a
     const GroupDesc *groupsF = nullptr, *groupsB = nullptr;
 };
 
-// which units a pass covers (SweepArgs::sel*): everything, or the rank's boundary / interior chains (overlapped exchange)
-struct PassSel {
-    int sel0 = 0, stride = 1, count = 0;   // count = 0: all
-    hipStream_t st = nullptr;
-    bool use_st = false, timed = true;
-};
-
-static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr,
-                    const PassSel *sel = nullptr)
+static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr)
 {
     SweepArgs a;
     a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = h->P; a.K = h->K;
     a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
     a.corr_top = with_corr ? h->dCorrTop : nullptr;
     a.corr_bot = with_corr ? h->dCorrBot : nullptr;
-    if (sel) { a.sel0 = sel->sel0; a.selstride = sel->stride; a.selcount = sel->count; }
-    hipStream_t st = (sel && sel->use_st) ? sel->st : h->stream;
+    hipStream_t st = h->stream;
     const int ng = (int)h->groups.size();
-    const bool prof = h->profile != 0 && (!sel || sel->timed);
+    const bool prof = h->profile != 0;
     auto rec = [&](bool start) {
         if (!prof) return;
         if (h->nev >= (int)h->evs.size()) {
@@ -1097,58 +1073,63 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     const bool coupled = h->variant == SPIKE_VARIANT_COUPLED;
     const int nif = coupled ? h->nif : h->nif_int;  // decoupled: only the cuts inside the caller's partitions
     const bool multi = coupled && nif > 0 && exchanging(h);
-    // units the sweep launches are made of: groups of CPW chains (tile kernels) or single chains (scan kernels)
-    const int nunits = h->cfg.scan ? h->P : (int)h->groups.size();
-    if (multi && h->overlap && nunits >= 3) {
-        // The exchange needs only the top tip of the rank's FIRST chain and the bottom tip of its LAST chain.  Those two
-        // (build_chains made them shorter than the interior chains) are swept on a second stream, which then copies the
-        // tips and runs the all-gather while the interior chains still sweep on the main stream; the streams join before
-        // the interface solves.  Same kernels on the same data: the result is bit-identical to the serial order.
+    const int K = h->K, P = h->P;
+    if ((rc = run_pass(h, x, y, false))) return rc;
+    if (nif <= 0) return SPIKE_OK;
+    // interfaces: [0, nloc) lie between two chains of this rank, [nloc, nif) are shared with the neighbouring ranks and
+    // need the exchanged tips ([g_top(first chain) | g_bottom(last chain)] = the first and last K entries of y)
+    const int nloc = multi ? P - 1 : nif, nedge = nif - nloc;
+    const IfaceDesc *ifs = h->spike_m > 0 ? (coupled ? h->dIfsFast : h->dIfsFastInt) : (coupled ? h->dIfs : h->dIfsInt);
+    // (with spike windows that overlap inside a chain a correction of one chain end can reach the other end's tip rows,
+    //  which the exchange stream still reads: serial order then)
+    const bool overlap = multi && h->overlap && (h->spike_m == 0 || 2 * h->spike_m <= h->min_chain_rows);
+    hipStream_t sx = st;   // stream of the exchange and of the work that depends on it
+    if (overlap) {
+        // The exchange is needed by the (at most two) rank-boundary interfaces and by the corrections they drive -- the
+        // top of the first chain, the bottom of the last.  Everything else of the coupling step (P - 1 local interface
+        // solves, the corrections of all other chain ends) runs on the main stream meanwhile: the all-gather's latency
+        // hides behind ~80 us of local work instead of standing between the sweeps and the interface solves.  Every
+        // element is computed by the same kernel code from the same operands as in the serial order: identical bits.
         if (!h->stream2) {
-            HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            // HIGH priority: the exchange is the critical path, and the runtime multiplexes the streams of one priority
+            // level onto a few hardware queues -- a second normal-priority stream was observed to share the main
+            // stream's queue (rocprofv3 Queue_Id), which serialises the two; another level has queues of its own.
+            int pr_least = 0, pr_greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+            HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr_greatest));
             HIPCHK(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
         }
-        HIPCHK(hipEventRecord(h->evFork, st));           // x (and everything before this apply) is ready on the main stream
-        HIPCHK(hipStreamWaitEvent(h->stream2, h->evFork, 0));
-        PassSel edge, inner;
-        edge.sel0 = 0; edge.stride = nunits - 1; edge.count = 2; edge.st = h->stream2; edge.use_st = true; edge.timed = false;
-        inner.sel0 = 1; inner.stride = 1; inner.count = nunits - 2;
-        if ((rc = run_pass(h, x, y, false, nullptr, &edge))) return rc;
-        hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, h->stream2, y, h->n, h->K, h->dSend);
-        HIPCHK(hipGetLastError());
-        if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K, h->stream2))) return rc;
-        HIPCHK(hipEventRecord(h->evJoin, h->stream2));
-        if ((rc = run_pass(h, x, y, false, nullptr, &inner))) return rc;
-        HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));
-    } else {
-        if ((rc = run_pass(h, x, y, false))) return rc;
-        if (multi) {  // [g_top(first partition) | g_bottom(last partition)] = the first and last K entries of the local vector
-            hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, st, y, h->n, h->K, h->dSend);
-            HIPCHK(hipGetLastError());
-            if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * h->K))) return rc;
-        }
+        sx = h->stream2;
+        HIPCHK(hipEventRecord(h->evFork, st));
+        HIPCHK(hipStreamWaitEvent(sx, h->evFork, 0));
     }
-    if (nif > 0) {
-        const int K = h->K, P = h->P;
+    if (!coupled) {   // decoupled: tip solutions / corrections of the caller-level interfaces must read as zero
         if (h->spike_m > 0) {
-            // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
-            if (!coupled) {  // tip solutions of the caller-level interfaces must read as zero
-                HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
-                HIPCHK(hipMemsetAsync(h->dXt, 0, sizeof(double) * (P + 2) * K, st));
-            }
-            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfsFast : h->dIfsFastInt, y, st));
-            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st));
+            HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
+            HIPCHK(hipMemsetAsync(h->dXt, 0, sizeof(double) * (P + 2) * K, st));
         } else {
-            if (!coupled) {
-                HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
-                HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
-            }
-            HIPCHK(launch_iface_apply(K, nif, coupled ? h->dIfs : h->dIfsInt, y, st));
-            rc = run_pass(h, x, y, true);
-            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
+            HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
         }
     }
+    // main stream first (asynchronous launches): a collective call may hold the host for a moment
+    HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
+    if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
+        HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0));
+    if (multi) {
+        hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, sx, y, h->n, K, h->dSend);
+        HIPCHK(hipGetLastError());
+        if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K, sx))) return rc;
+        HIPCHK(launch_iface_apply(K, nedge, ifs + nloc, y, sx));
+        if (h->spike_m > 0)
+            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2));
+        if (overlap) {
+            HIPCHK(hipEventRecord(h->evJoin, sx));
+            HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));
+        }
+    }
+    if (h->spike_m == 0) return run_pass(h, x, y, true);   // re-solve with the corrected right-hand side
     return SPIKE_OK;
 }
 

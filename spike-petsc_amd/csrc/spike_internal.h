@@ -48,10 +48,6 @@ struct SweepArgs {
     const double *corr_top;  // [nchains*K] or null (forward only)
     const double *corr_bot;  // [nchains*K] or null
     int K;
-    // launch over a SUBSET of the workgroups' units (groups for k_sweep, chains for the scan kernels): unit index =
-    // sel0 + i * selstride for i in [0, selcount); selcount = 0: all.  The multi-rank apply sweeps the rank's first and
-    // last chain on a second stream (their tips feed the exchange) while the interior chains run on the main stream.
-    int sel0 = 0, selstride = 1, selcount = 0;
 };
 
 // One reduced (interface) system between partition "lo" and the partition below it.
@@ -122,7 +118,7 @@ hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc 
 hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
                                int *extent, hipStream_t st);
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st);
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0);
 
 hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hipStream_t st);
 

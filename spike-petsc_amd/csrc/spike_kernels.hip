@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane / R, lr = lane % R;
-    const int grp = a.sel0 + (int)blockIdx.x * a.selstride;
+    const int grp = blockIdx.x;
     const int p = grp * CPW + c;
     const bool valid = p < a.nchains;
     ChainDesc cd;
@@ -289,7 +289,6 @@ bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf)
 
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag)
 {
-    if (a.selcount > 0) ngroups = a.selcount;
     if (ngroups <= 0) return hipSuccess;
     const int dpw = (tag == 0 && cfg.sDPW > 0) ? cfg.sDPW : cfg.DPW, nw = (tag == 0 && cfg.sNW > 0) ? cfg.sNW : cfg.NW;
     const int pf = (tag == 0 && cfg.sPF > 0) ? cfg.sPF : cfg.basePF();
@@ -510,9 +509,8 @@ __global__ __launch_bounds__(256) void k_scan_sweep(SweepArgs s)
 {
     constexpr int U = 8;  // segments per iteration
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= (s.selcount > 0 ? s.selcount : s.nchains)) return;
-    const int p = s.sel0 + unit * s.selstride;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= s.nchains) return;
     const ChainDesc cd = s.chains[p];
     const double *coef = s.tiles;
     const int nseg = (cd.nrows + 63) / 64;
@@ -559,9 +557,8 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 {
     constexpr int U = 8;
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= (s.selcount > 0 ? s.selcount : s.nchains)) return;
-    const int p = s.sel0 + unit * s.selstride;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= s.nchains) return;
     const ChainDesc cd = s.chains[p];
     const double *lcoef = s.tiles;
     const int nseg = (cd.nrows + 63) / 64;   // host guarantees nseg <= MAXSEG
@@ -624,7 +621,6 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
 // forward + backward in one launch when every chain fits the register-resident form (max_rows <= 64 segments)
 hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, const double *cu, hipStream_t st, int tag)
 {
-    if (a.selcount > 0) nchains = a.selcount;
     if (nchains <= 0) return hipSuccess;
     const dim3 g((nchains + 3) / 4), b(256);
     if (max_rows <= 32 * 64) {
@@ -639,7 +635,6 @@ hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, cons
 
 hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag)
 {
-    if (a.selcount > 0) nchains = a.selcount;
     if (nchains <= 0) return hipSuccess;
     const dim3 g((nchains + 3) / 4), b(256);
     if (tag == 0) {
@@ -1797,11 +1792,15 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 // x[top m rows of chain p]    -= W_p x_b(p-1)   (xb slot p;   slot 0   = the previous rank's last partition)
 // x[bottom m rows of chain p] -= V_p x_t(p+1)   (xt slot p+2; slot P+1 = the next rank's first partition)
 // lane = row (coalesced column-major spike reads), K sequential FMAs per lane, tip vectors from LDS.
-__global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const ChainDesc *chains, const double *Wf,
-                                                       const double *Vf, const double *xb, const double *xt, double *x)
+// mode 0: every (chain, end); 1: all but the two rank-boundary ends (top of chain 0, bottom of the last chain), whose tip
+// solutions come from the exchange; 2: exactly those two (launched on the exchange stream once they are known).
+__global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf,
+                                                       const double *Vf, const double *xb, const double *xt, double *x, int mode)
 {
     extern __shared__ double tip[];
-    const int p = blockIdx.y, which = blockIdx.z;
+    int p = blockIdx.y, which = blockIdx.z;
+    if (mode == 2) { which = blockIdx.y; p = which == 0 ? 0 : nchains - 1; }
+    else if (mode == 1 && ((p == 0 && which == 0) || (p == nchains - 1 && which == 1))) return;
     const ChainDesc cd = chains[p];
     const double *src = which == 0 ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
     for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = src[c];
@@ -1836,11 +1835,12 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
 }
 
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st)
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spike_correct, dim3((m + 511) / 512, nchains, 2), dim3(256), (size_t)K * sizeof(double), st, K, m,
-                       chains, Wf, Vf, xb, xt, x);
+    const dim3 grid = mode == 2 ? dim3((m + 511) / 512, 2, 1) : dim3((m + 511) / 512, nchains, 2);
+    hipLaunchKernelGGL(k_spike_correct, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf, xb,
+                       xt, x, mode);
     return hipGetLastError();
 }
 

@@ -95,10 +95,10 @@ def test_unequal_row_blocks_take_the_same_collective_branches(spike, oracle, del
 
 @pytest.mark.parametrize("G,N,K", [(2, 65536, 16), (3, 98304, 40), (2, 131072, 128), (2, 32768, 1), (2, 65536, 4)])
 def test_overlapped_exchange_is_bit_identical_and_exact(spike, oracle, G, N, K):
-    """Automatic partitioning on several ranks: the rank-boundary chains are shortened and swept on a second stream
-    with the all-gather behind them while the interior chains run (boundary first, exchange overlapped).
-    Same kernels on the same data in another launch order: bit-identical to the serial order; and on this dominant
-    system truncated SPIKE equals the exact band solve."""
+    """Several ranks: the tip exchange (all-gather), the rank-boundary interface solves and the corrections they drive
+    run on a second stream while the local interface solves and corrections run on the main one (the
+    collective overlaps local work).  Same kernel code on the same operands in another launch order: bit-identical to
+    the serial order; and on this dominant system truncated SPIKE equals the exact band solve."""
     import torch
     band = oracle.gen_band(N, K, delta=1.2)
     f = oracle.gen_vec(N)

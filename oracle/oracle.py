@@ -37,7 +37,7 @@ def lib(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    so = path or os.path.join(_HERE, "liboracle.so")
+    so = path or os.environ.get("SPIKE_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # env: the sanitizer build
     if not os.path.exists(so):
         build()
     L = C.CDLL(so)

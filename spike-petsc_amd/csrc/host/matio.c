@@ -60,9 +60,13 @@ PetscErrorCode MatLoad(const char *path, Mat *A)
     }
     PetscInt *ia = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(M + 1)), *ja = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(nz > 0 ? nz : 1));
     PetscScalar *a = (PetscScalar *)malloc(sizeof(PetscScalar) * (size_t)(nz > 0 ? nz : 1));
+    if (!ia || !ja || !a) {   /* the sizes come from the file header: a damaged header must not become a null dereference */
+        free(ia); free(ja); free(a); fclose(f);
+        return PETSC_ERR_MEM;
+    }
     int bad = 0;
     ia[0] = 0;
-    for (int32_t i = 0; i < M && !bad; ++i) { int32_t l; bad = rd_be32(f, &l) || l < 0; ia[i + 1] = ia[i] + l; }
+    for (int32_t i = 0; i < M && !bad; ++i) { int32_t l = 0; bad = rd_be32(f, &l) || l < 0; ia[i + 1] = ia[i] + (bad ? 0 : l); }
     if (!bad && ia[M] != nz) bad = 1;
     for (int32_t k = 0; k < nz && !bad; ++k) { int32_t c; bad = rd_be32(f, &c) || c < 0 || c >= N; ja[k] = c; }
     for (int32_t k = 0; k < nz && !bad; ++k) bad = rd_be64f(f, &a[k]);
@@ -112,7 +116,9 @@ PetscErrorCode MatLoadMatrixMarket(const char *path, Mat *A)
     do { if (!fgets(line, sizeof line, f)) { fclose(f); return PETSC_ERR_ARG_WRONG; } } while (line[0] == '%' || line[0] == '\n');
     long long M, N, nz;
     if (sscanf(line, "%lld %lld %lld", &M, &N, &nz) != 3 || M <= 0 || M != N || nz < 0) { fclose(f); return PETSC_ERR_ARG_WRONG; }
+    if (M > 2000000000LL || nz > (1LL << 40)) { fclose(f); return PETSC_ERR_ARG_OUTOFRANGE; }
     trip_t *t = (trip_t *)malloc(sizeof(trip_t) * (size_t)(2 * nz + 1));
+    if (!t) { fclose(f); return PETSC_ERR_MEM; }
     PetscInt cnt = 0;
     for (long long k = 0; k < nz; ++k) {
         long long i, j;
@@ -127,6 +133,7 @@ PetscErrorCode MatLoadMatrixMarket(const char *path, Mat *A)
     qsort(t, (size_t)cnt, sizeof(trip_t), trip_cmp);
     PetscInt *ia = (PetscInt *)calloc((size_t)(M + 1), sizeof(PetscInt)), *ja = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(cnt > 0 ? cnt : 1));
     PetscScalar *a = (PetscScalar *)malloc(sizeof(PetscScalar) * (size_t)(cnt > 0 ? cnt : 1));
+    if (!ia || !ja || !a) { free(ia); free(ja); free(a); free(t); return PETSC_ERR_MEM; }
     PetscInt q = 0;
     for (PetscInt k = 0; k < cnt; ++k) {
         if (q > 0 && k > 0 && t[k].r == t[k - 1].r && t[k].c == t[k - 1].c) { a[q - 1] += t[k].v; continue; } /* duplicates add */

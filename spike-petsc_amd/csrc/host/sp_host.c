@@ -751,13 +751,20 @@ static PetscErrorCode KSPSolve_GMRES(KSP ksp)
     if (ksp->vec_rhs->n != n || ksp->vec_sol->n != n) return seterr(PETSC_ERR_ARG_SIZ, "KSPSolve: vector size");
     if (spike_set_operator_csr(h, n, A->ia, A->ja, A->a) < 0) return seterr(PETSC_ERR_LIB, "libspike_mi355: %s", spike_last_error(h));
     void *db = NULL, *dx = NULL;
-    if (spike_dev_malloc(&db, sizeof(double) * (size_t)n) || spike_dev_malloc(&dx, sizeof(double) * (size_t)n)) return seterr(PETSC_ERR_MEM, "device allocation");
+    if (spike_dev_malloc(&db, sizeof(double) * (size_t)n) || spike_dev_malloc(&dx, sizeof(double) * (size_t)n)) {
+        if (db) spike_dev_free(db);
+        spike_clear_operator(h);
+        return seterr(PETSC_ERR_MEM, "device allocation");
+    }
     spike_dev_upload(db, ksp->vec_rhs->a, sizeof(double) * (size_t)n);
     spike_dev_upload(dx, ksp->vec_sol->a, sizeof(double) * (size_t)n);
     {   /* PETSc's -ksp_gmres_cgs_refinement_type refine_never|refine_ifneeded|refine_always (default refine_never) */
         char rt[32];
-        if (opt_str(ksp->prefix, "ksp_gmres_cgs_refinement_type", rt, sizeof rt) && spike_set_option(h, "gmres_cgs_refinement_type", rt))
+        if (opt_str(ksp->prefix, "ksp_gmres_cgs_refinement_type", rt, sizeof rt) && spike_set_option(h, "gmres_cgs_refinement_type", rt)) {
+            spike_dev_free(db); spike_dev_free(dx);   /* every exit releases the device vectors and the CSR operator */
+            spike_clear_operator(h);
             return seterr(PETSC_ERR_ARG_OUTOFRANGE, "libspike_mi355: %s", spike_last_error(h));
+        }
     }
     int its = 0;
     double rn = 0, ms = 0;

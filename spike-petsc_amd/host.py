@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__)) if "__file__" in globals() else os.getcwd()
-HOST_LIB_PATH = os.path.join(_HERE, "libspike_petsc_host.so")
+# SPIKE_HOST_LIB selects another build of the same sources (the address/UB-sanitizer build, tools/run_asan_tests.sh)
+HOST_LIB_PATH = os.environ.get("SPIKE_HOST_LIB") or os.path.join(_HERE, "libspike_petsc_host.so")
 
 i64 = C.c_int64
 i64p = C.POINTER(C.c_int64)

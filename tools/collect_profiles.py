@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of one tools/r2_profile.sh run from gpurun_out/prof_<tag>/ (scratch) into profiles/ (tracked).
+usage: tools/collect_profiles.py <tag>"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = "profiles"
+for name in ["bench", "n2097152", "n1048576", "n524288", "c2"]:
+    f = glob.glob(os.path.join(src, "stats_" + name, "*", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
+for name in ["bench_line.json", "bench_line_under_rocprof.json", "pmc_summary.json", "rank_n2097152.json", "rank_n1048576.json",
+             "rank_n524288.json", "c2.json"]:
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
+pm = os.path.join(src, "pmc_summary.json")
+if os.path.exists(pm):
+    d = json.load(open(pm))
+    tot = 0.0
+    ks = []
+    for k, v in d["kernels"].items():
+        if "k_sweep<" in k and k.rstrip().endswith("0>(spike::SweepArgs)"):
+            tot += v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+            ks.append(k)
+    line = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
+    json.dump({"N": line["config"]["N"], "K": line["config"]["K"], "P": line["config"]["partitions"], "traffic_per_pass_bytes": tot,
+               "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; reads x2 per "
+                         "MI355X_MICROARCH.md HBM section); kernels: %s" % (tag, " + ".join(ks))},
+              open(os.path.join(dst, "pmc_current.json"), "w"), indent=1)
+print(sorted(os.listdir(dst)))

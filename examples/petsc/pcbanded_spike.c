@@ -9,6 +9,8 @@
  *
  *   link: -I<repo>/include -L<repo>/spike-petsc_amd -lspike_mi355
  *   run : -pc_type banded -pc_banded_kmax 128 -banded_spike_partitions 0 -banded_spike_variant coupled
+ *         mpiexec -n 8 (one rank per GPU, MATMPIAIJ): the row blocks go through spike_setup_csr_dist, the rank-boundary
+ *         interface systems are assembled by the library's RCCL all-gather.  The KSP-level hook is kspreorder_spike.c.
  */
 #include <petsc/private/pcimpl.h>
 #include <petscdevice_hip.h>
@@ -18,7 +20,8 @@ typedef struct {
   PetscInt     kmax, k;   /* :112 */
   PetscReal    frac, f;   /* :113 */
   spike_handle spike;     /* replaces Mat B (:114) and PC pc (:115): the band lives in the library */
-  PetscBool    comm_done;
+  PetscBool    comm_done;                 /* spike_comm_init done for this PC's communicator */
+  PetscBool    refactor_on_same_pattern;  /* -pc_banded_refactor: values changed, pattern did not */
 } PC_Banded;
 
 #define SPIKE_CHK(pc, b, call) \
@@ -56,6 +59,7 @@ static PetscErrorCode PCSetFromOptions_Banded(PC pc, PetscOptionItems *PetscOpti
   PetscOptionsHeadBegin(PetscOptionsObject, "Banded options");
   PetscCall(PetscOptionsInt("-pc_banded_kmax", "Maximum half-bandwidth", "PCBandedSetMaxHalfBandwidth", b->kmax, &b->kmax, NULL));
   PetscCall(PetscOptionsReal("-pc_banded_frac", "Fraction of the 1-norm to keep", "PCBandedSetNormFraction", b->frac, &b->frac, NULL));
+  PetscCall(PetscOptionsBool("-pc_banded_refactor", "Re-extract and re-factor when only the values changed", NULL, b->refactor_on_same_pattern, &b->refactor_on_same_pattern, NULL));
   /* the inner PC's options (prefix banded_, :281) become the engine's options */
   PetscCall(PetscOptionsInt("-banded_spike_partitions", "SPIKE partitions (0 = automatic)", NULL, P, &P, &set));
   if (set) { PetscCall(PetscSNPrintf(num, sizeof num, "%" PetscInt_FMT, P)); SPIKE_CHK(pc, b, spike_set_option(b->spike, "partitions", num)); }
@@ -67,34 +71,62 @@ static PetscErrorCode PCSetFromOptions_Banded(PC pc, PetscOptionItems *PetscOpti
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
+/* One rank per GPU: join the ranks of the PC's communicator once (the unique id travels by MPI, the data path is RCCL). */
+static PetscErrorCode PCBandedJoinRanks(PC pc)
+{
+  PC_Banded  *b = (PC_Banded *)pc->data;
+  MPI_Comm    comm = PetscObjectComm((PetscObject)pc);
+  PetscMPIInt size, rank;
+  char        id[SPIKE_UNIQUE_ID_BYTES];
+
+  PetscFunctionBegin;
+  if (b->comm_done) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCallMPI(MPI_Comm_size(comm, &size));
+  PetscCallMPI(MPI_Comm_rank(comm, &rank));
+  if (size > 1) {
+    if (rank == 0) PetscCheck(spike_comm_unique_id(id) == 0, comm, PETSC_ERR_LIB, "spike_comm_unique_id: cannot load librccl");
+    PetscCallMPI(MPI_Bcast(id, SPIKE_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm));
+    SPIKE_CHK(pc, b, spike_comm_init(b->spike, (int)size, (int)rank, id)); /* must precede setup */
+  }
+  b->comm_done = PETSC_TRUE;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
 static PetscErrorCode PCSetUp_Banded(PC pc) /* :165-180 */
 {
   PC_Banded      *b = (PC_Banded *)pc->data;
+  Mat             Aloc = pc->pmat;   /* the rows this rank owns, as one SeqAIJ with GLOBAL column indices */
   const PetscInt *ia, *ja;
   PetscScalar    *a;
-  PetscInt        n;
-  PetscBool       done;
-  PetscMPIInt     size, rank;
+  PetscInt        n, N, rstart, rend;
+  PetscBool       done, ismpi;
   int             k;
   double          f;
 
   PetscFunctionBegin;
-  PetscCallMPI(MPI_Comm_size(PetscObjectComm((PetscObject)pc), &size));
-  PetscCallMPI(MPI_Comm_rank(PetscObjectComm((PetscObject)pc), &rank));
-  PetscCheck(size == 1, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP,
-             "CSR entry is single-rank; for one rank per GPU extract the local band and call spike_comm_init + spike_setup_band (INTEGRATION.md section 2)");
+  /* The reference extracts the band on the first call only (pc->setupcalled == 0, :171) and re-runs the inner
+     PCSetUp every time (:178).  Here extraction + factorisation are one library call, made when the operator is new:
+     first call, or PETSc flagged a changed matrix (pc->flag != SAME_PRECONDITIONER path reaches setup again). */
+  if (pc->setupcalled && pc->flag == SAME_NONZERO_PATTERN && !b->refactor_on_same_pattern) PetscFunctionReturn(PETSC_SUCCESS);
+  PetscCall(PCBandedJoinRanks(pc));
+  PetscCall(MatGetSize(pc->pmat, &N, NULL));
+  PetscCall(MatGetOwnershipRange(pc->pmat, &rstart, &rend)); /* :36 */
+  PetscCall(PetscObjectTypeCompare((PetscObject)pc->pmat, MATMPIAIJ, &ismpi));
+  if (ismpi) PetscCall(MatMPIAIJGetLocalMat(pc->pmat, MAT_INITIAL_MATRIX, &Aloc)); /* diagonal + off-diagonal block merged, global columns (:74-75) */
   /* MatCreateSubMatrixBanded (:22-107) + PCSetUp(b->pc) (:178) in one call: the library applies the reference's
-     half-bandwidth rule to the CSR arrays and factors the extracted band on the GPU.  Needs --with-64-bit-indices
-     (PetscInt = int64_t); otherwise widen ia/ja first. */
-  PetscCall(MatGetRowIJ(pc->pmat, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
-  PetscCheck(done, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "MatGetRowIJ failed");
-  PetscCall(MatSeqAIJGetArray(pc->pmat, &a));
+     half-bandwidth rule to the CSR arrays (per-rank sums combined in rank order) and factors the extracted band on the
+     GPU.  Needs --with-64-bit-indices (PetscInt = int64_t); otherwise widen ia/ja first. */
+  PetscCall(MatGetRowIJ(Aloc, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
+  PetscCheck(done && n == rend - rstart, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "MatGetRowIJ failed");
+  PetscCall(MatSeqAIJGetArray(Aloc, &a));
   b->k = b->kmax; b->f = b->frac; /* :172-173 */
-  SPIKE_CHK(pc, b, spike_setup_csr(b->spike, (int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a, (int)b->kmax, (double)b->frac, &k, &f));
+  SPIKE_CHK(pc, b, spike_setup_csr_dist(b->spike, (int64_t)N, (int64_t)rstart, (int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a,
+                                        (int)b->kmax, (double)b->frac, &k, &f));
   b->k = k; b->f = f;
   PetscCall(PetscInfo(pc, "PCBANDED: half-bandwidth: %d norm fraction: %g\n", k, f)); /* :175 */
-  PetscCall(MatSeqAIJRestoreArray(pc->pmat, &a));
-  PetscCall(MatRestoreRowIJ(pc->pmat, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
+  PetscCall(MatSeqAIJRestoreArray(Aloc, &a));
+  PetscCall(MatRestoreRowIJ(Aloc, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
+  if (ismpi) PetscCall(MatDestroy(&Aloc));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -136,6 +168,7 @@ PETSC_EXTERN PetscErrorCode PCCreate_Banded(PC pc) /* :251-283 */
   PetscCall(PetscNew(&b));
   pc->data = (void *)b;
   b->kmax = 50;   /* :261 */
+  b->refactor_on_same_pattern = PETSC_TRUE;
   b->frac = 0.95; /* :262 */
   PetscCheck(spike_create(&b->spike) == 0, PetscObjectComm((PetscObject)pc), PETSC_ERR_LIB, "spike_create: no HIP device");
   pc->ops->apply               = PCApply_Banded;

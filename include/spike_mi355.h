@@ -8,7 +8,8 @@
  *   spike_create / spike_destroy   PCCreate(...,&b->pc) src/matbanded.c:278, PCDestroy(&b->pc) :142
  *   spike_set_option               PCSetFromOptions(b->pc) src/matbanded.c:159 (options prefix "banded_", :281)
  *   spike_setup_band               PCSetOperators(b->pc,pc->mat,b->B)+PCSetUp(b->pc) src/matbanded.c:176-178
- *   spike_setup_csr                MatCreateSubMatrixBanded + PCSetUp(b->pc)  src/matbanded.c:22-107,174-178
+ *   spike_setup_csr[_dist]         MatCreateSubMatrixBanded + PCSetUp(b->pc)  src/matbanded.c:22-107,174-178
+ *                                  (_dist: row-block MPI layout, MatGetOwnershipRange :36)
  *   spike_apply                    PCApply(b->pc,x,y) src/matbanded.c:190   (the metric's "PCApply")
  *   spike_reset                    PCReset(b->pc) src/matbanded.c:127
  *   spike_view                     PCView(b->pc,viewer) src/matbanded.c:207
@@ -121,6 +122,14 @@ int spike_setup_band(spike_handle h, int64_t n_global, int64_t row0, int64_t n_l
 int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
                     int kmax, double frac, int *k_out, double *frac_out);
 
+/* CSR entry for a ROW-BLOCK-DISTRIBUTED matrix, one rank per GPU (the layout MatCreateSubMatrixBanded is written for:
+ * MatGetOwnershipRange src/matbanded.c:36, diagonal/off-diagonal split :74-75): this rank passes its rows
+ * [row0, row0+n_local) with GLOBAL 0-based column indices (ia has n_local+1 entries starting at 0).  Collective over the
+ * ranks joined by spike_comm_init: the per-diagonal weights of the reference's rule are summed per rank in row order and
+ * combined in rank order, so every rank chooses the same k.  One rank: identical to spike_setup_csr.            */
+int spike_setup_csr_dist(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia,
+                         const int64_t *ja, const double *a, int kmax, double frac, int *k_out, double *frac_out);
+
 /* ---- apply --------------------------------------------------------------------------- */
 /* y = M^{-1} x on the local rows.  x != y.  on_device != 0: device pointers, asynchronous on
  * the handle's stream; otherwise host pointers, synchronous.                               */
@@ -158,6 +167,11 @@ int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja, const doub
                      int *k_out, double *frac_out);
 int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int K, double *band,
                       int64_t ld);
+/* pieces of the distributed rule: one rank's weights w[0..kmax) and its part of ||A||_1 (src/matbanded.c:38-49), and
+ * the stopping rule on summed weights (:53-56, 104-105) */
+int spike_csr_band_weights(int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia, const int64_t *ja,
+                           const double *a, int kmax, double *w, double *normA);
+int spike_band_rule(int64_t n, const double *w, double normA, int kmax, double frac, int *k_out, double *frac_out);
 
 /* ---- helpers (device) ----------------------------------------------------------------------- */
 /* y = A x with the band kept at setup (device pointers, local rows; halo via RCCL when nranks>1) */

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "spike_set_operator_csr", "spike_clear_operator", "spike_dev_malloc", "spike_dev_free", "spike_dev_upload",
     "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band", "spike_measure_read_bw",
     "spike_set_operator_band", "spike_operator_matvec", "spike_auto_partitions",
+    "spike_setup_csr_dist", "spike_csr_band_weights", "spike_band_rule",
 ]
 
 
@@ -91,6 +92,10 @@ def lib():
     L.spike_setup_band.argtypes = [vp, i64, i64, i64, C.c_int, vp, i64, C.c_int]
     L.spike_setup_csr.argtypes = [vp, i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                   C.POINTER(C.c_double)]
+    L.spike_setup_csr_dist.argtypes = [vp, i64, i64, i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_double)]
+    L.spike_csr_band_weights.argtypes = [i64, i64, i64, iptr, iptr, dptr, C.c_int, dptr, dptr]
+    L.spike_band_rule.argtypes = [i64, dptr, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.spike_apply.argtypes = [vp, vp, vp, C.c_int]
     L.spike_gmres.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int),
                               C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -198,6 +203,17 @@ class Spike:
         f = C.c_double(0)
         self._chk(self.L.spike_setup_csr(self.h, n, ia.ctypes.data_as(iptr), ja.ctypes.data_as(iptr),
                                          a.ctypes.data_as(dptr), kmax, frac, C.byref(k), C.byref(f)))
+        return k.value, f.value
+
+    def setup_csr_dist(self, n_global, row0, ia, ja, a, kmax=50, frac=0.95):
+        """this rank's rows [row0, row0 + len(ia) - 1) of a row-block-distributed CSR matrix, global column indices"""
+        ia = np.ascontiguousarray(ia, dtype=np.int64)
+        ja = np.ascontiguousarray(ja, dtype=np.int64)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        k = C.c_int(0)
+        f = C.c_double(0)
+        self._chk(self.L.spike_setup_csr_dist(self.h, n_global, row0, len(ia) - 1, ia.ctypes.data_as(iptr), ja.ctypes.data_as(iptr),
+                                              a.ctypes.data_as(dptr), kmax, frac, C.byref(k), C.byref(f)))
         return k.value, f.value
 
     def apply(self, x, y=None):

@@ -34,6 +34,44 @@ extern "C" int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja,
     return SPIKE_OK;
 }
 
+// Row-block-distributed form of the weight pass (the reference's extraction is written for PETSc's row-block MPI
+// layout: MatGetOwnershipRange src/matbanded.c:36, the |r - c| <= k split into diagonal/off-diagonal blocks :74-75; its
+// weight Vec, however, is indexed locally (:45), so its own multi-rank result is not defined -- SURVEY.md section 2).
+// This rank's rows [row0, row0 + n_local), GLOBAL columns: w[d] for d in [0, kmax) and the local part of ||A||_1, summed
+// in the reference's row order.  The caller combines the ranks' parts in rank order (spike_setup_csr_dist).
+extern "C" int spike_csr_band_weights(int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia, const int64_t *ja,
+                                      const double *a, int kmax, double *w /* kmax */, double *normA)
+{
+    if (n_global <= 0 || row0 < 0 || n_local < 0 || row0 + n_local > n_global || !ia || !ja || !a || kmax < 0 || !normA || (kmax > 0 && !w))
+        return SPIKE_ERR_ARG;
+    for (int k = 0; k < kmax; ++k) w[k] = 0.0;
+    double na = 0.0;
+    for (int64_t r = 0; r < n_local; ++r)
+        for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
+            if (ja[p] < 0 || ja[p] >= n_global) return SPIKE_ERR_ARG;
+            const int64_t gr = row0 + r, d = gr > ja[p] ? gr - ja[p] : ja[p] - gr;
+            if (d < kmax) w[d] += std::fabs(a[p]);
+            na += std::fabs(a[p]);
+        }
+    *normA = na;
+    return SPIKE_OK;
+}
+
+// the stopping rule of src/matbanded.c:53-56 on already summed weights (w[d] for d < min(kmax, n))
+extern "C" int spike_band_rule(int64_t n, const double *w, double normA, int kmax, double frac, int *k_out, double *frac_out)
+{
+    if (!k_out || !frac_out || kmax < 0 || (kmax > 0 && !w)) return SPIKE_ERR_ARG;
+    double normB = 0.0;
+    int k;
+    for (k = 0; k < kmax; ++k) {
+        if (k < n) normB += w[k];
+        if (normB >= frac * normA) break;
+    }
+    *k_out = k;
+    *frac_out = normB / normA;
+    return SPIKE_OK;
+}
+
 extern "C" int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int K, double *band,
                                  int64_t ld)
 {

@@ -26,6 +26,9 @@ using namespace spike;
 
 extern "C" int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int kmax, double frac,
                                 int *k_out, double *frac_out);
+extern "C" int spike_csr_band_weights(int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia, const int64_t *ja,
+                                      const double *a, int kmax, double *w, double *normA);
+extern "C" int spike_band_rule(int64_t n, const double *w, double normA, int kmax, double frac, int *k_out, double *frac_out);
 
 // ---- RCCL through dlopen: the library has no link-time dependency on librccl ----------------
 typedef struct ncclComm *ncclComm_t_;
@@ -1504,35 +1507,65 @@ extern "C" int spike_dev_download(void *dst, const void *src, size_t bytes) { re
 // The half-bandwidth rule runs on the host in the reference's own pass order (spike_csr_band_k: bit-identical k and
 // fraction); the matrix itself goes to the device as CSR (nnz entries over PCIe, not (2k+1) n) and is scattered into the
 // diagonal-major band there.
-extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
-                               int kmax, double frac, int *k_out, double *frac_out)
+extern "C" int spike_setup_csr_dist(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia,
+                                    const int64_t *ja, const double *a, int kmax, double frac, int *k_out, double *frac_out)
 {
-    if (!h || n <= 0 || !ia || !ja || !a) return SPIKE_ERR_ARG;
-    if (h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "spike_setup_csr is single-rank; use spike_setup_band per rank");
-    if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "matrix too large");
+    if (!h || n_global <= 0 || n_local <= 0 || row0 < 0 || row0 + n_local > n_global || !ia || !ja || !a || kmax < 0)
+        return fail(h, SPIKE_ERR_ARG, "spike_setup_csr_dist: bad sizes");
+    if (n_local > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "matrix too large");
+    if (h->nranks == 1 && (row0 != 0 || n_local != n_global)) return fail(h, SPIKE_ERR_ARG, "single rank must own all rows");
+    hipStream_t st = h->stream;
     int k = 0;
     double f = 0.0;
-    int rc = spike_csr_band_k(n, ia, ja, a, kmax, frac, &k, &f);
-    if (rc) return fail(h, rc, "band rule failed (column index out of range?)");
-    const int64_t nnz = ia[n];
+    int rc;
+    if (!exchanging(h)) {
+        rc = spike_csr_band_k(n_global, ia, ja, a, kmax, frac, &k, &f);   // the reference's own sequential sums
+        if (rc) return fail(h, rc, "band rule failed (column index out of range?)");
+    } else {
+        // every rank sums its rows' weights in row order; the parts are all-gathered and added in RANK order on every
+        // rank, so all ranks hold the same w (bitwise) and choose the same k
+        const int nw = kmax + 1;   // [w[0..kmax) | normA]
+        std::vector<double> part((size_t)nw, 0.0), all((size_t)nw * h->nranks, 0.0);
+        rc = spike_csr_band_weights(n_global, row0, n_local, ia, ja, a, kmax, part.data(), &part[(size_t)kmax]);
+        // a rank with bad input must still join the collective: it flags itself with a NaN norm
+        if (rc) part[(size_t)kmax] = std::nan("");
+        TmpPool tp;
+        double *dpart = nullptr, *dall = nullptr;
+        HIPCHK(tp.alloc(&dpart, (size_t)nw));
+        HIPCHK(tp.alloc(&dall, (size_t)nw * h->nranks));
+        HIPCHK(hipMemcpyAsync(dpart, part.data(), sizeof(double) * nw, hipMemcpyHostToDevice, st));
+        int rc2 = coll_allgather(h, dpart, dall, (size_t)nw);
+        if (rc2) return rc2;
+        HIPCHK(hipMemcpyAsync(all.data(), dall, sizeof(double) * nw * h->nranks, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<double> w((size_t)(kmax > 0 ? kmax : 1), 0.0);
+        double normA = 0.0;
+        for (int r = 0; r < h->nranks; ++r) {
+            for (int d = 0; d < kmax; ++d) w[(size_t)d] += all[(size_t)r * nw + d];
+            normA += all[(size_t)r * nw + kmax];
+        }
+        if (normA != normA) return fail(h, SPIKE_ERR_ARG, "band rule failed on some rank (column index out of range?)");
+        if ((rc = spike_band_rule(n_global, w.data(), normA, kmax, frac, &k, &f))) return fail(h, rc, "band rule failed");
+    }
+    const int64_t nnz = ia[n_local];
     std::vector<int32_t> j32((size_t)nnz);
     for (int64_t q = 0; q < nnz; ++q) j32[(size_t)q] = (int32_t)ja[q];
     TmpPool tmp;
     int64_t *dia = nullptr;
     int32_t *dja = nullptr;
     double *da = nullptr, *dband = nullptr;
-    HIPCHK(tmp.alloc(&dia, (size_t)n + 1));
+    HIPCHK(tmp.alloc(&dia, (size_t)n_local + 1));
     HIPCHK(tmp.alloc(&dja, (size_t)nnz));
     HIPCHK(tmp.alloc(&da, (size_t)nnz));
-    HIPCHK(tmp.alloc(&dband, (size_t)(2 * k + 1) * (size_t)n));
-    HIPCHK(hipMemcpyAsync(dia, ia, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dja, j32.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(launch_csr_to_band(n, dia, dja, da, k, dband, n, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(tmp.alloc(&dband, (size_t)(2 * k + 1) * (size_t)n_local));
+    HIPCHK(hipMemcpyAsync(dia, ia, sizeof(int64_t) * (n_local + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dja, j32.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
+    HIPCHK(launch_csr_to_band(n_local, dia, dja, da, k, dband, n_local, st, row0));
+    HIPCHK(hipStreamSynchronize(st));
     const int keep = h->keep_band;
     h->keep_band = 1;  // dband is scratch: the library must hold its own copy
-    rc = setup_impl(h, n, 0, n, k, dband, n, 1);
+    rc = setup_impl(h, n_global, row0, n_local, k, dband, n_local, 1);
     h->keep_band = keep;
     if (rc) return rc;
     h->k_extracted = k;
@@ -1540,6 +1573,13 @@ extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, con
     if (k_out) *k_out = k;
     if (frac_out) *frac_out = f;
     return SPIKE_OK;
+}
+
+extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
+                               int kmax, double frac, int *k_out, double *frac_out)
+{
+    if (h && h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "several ranks: every rank passes its row block to spike_setup_csr_dist");
+    return spike_setup_csr_dist(h, n, 0, n, ia, ja, a, kmax, frac, k_out, frac_out);
 }
 
 // ---- introspection ---------------------------------------------------------------------------------------------

@@ -147,3 +147,45 @@ def test_sharded_gmres_and_matvec(spike, oracle):
     xo, ito, rno, hist, oko = oracle.gmres(band, b, oracle.Spike(band, G * Pl), variant=0, rtol=1e-8, maxit=200)
     assert abs(res[0][2] - ito) <= 1
     assert np.linalg.norm(x - u) <= 1e-6 * np.linalg.norm(u)
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_row_block_distributed_csr_entry_equals_single_rank(spike, oracle, G):
+    """spike_setup_csr_dist: every rank passes its row block (global columns) -- the layout MatCreateSubMatrixBanded is
+    written for (/root/reference/src/matbanded.c:36, 74-75).  All ranks choose the single-rank k, the fraction agrees to
+    rounding (per-rank sums combined in rank order), and the sharded apply equals the single-rank CSR entry and the oracle."""
+    import torch
+    import scipy.sparse as sps
+    rng = np.random.default_rng(7)
+    n, Pl = 6016 * 2, 4
+    offs = list(range(-30, 31)) + [-200, 333]                   # a band plus two far diagonals the rule must cut off
+    diags = [rng.uniform(-1, 1, n - abs(o)) * (0.6 ** min(abs(o), 40)) for o in offs]
+    A = sps.diags(diags, offs, shape=(n, n), format="csr")
+    A.setdiag(3.0)
+    A = sps.csr_matrix(A)
+    A.sort_indices()
+    ia, ja, a = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data
+    rhs = oracle.gen_vec(n)
+    cuts = _split(n, G)
+    single = spike.Spike(partitions=G * Pl)
+    k1, f1 = single.setup_csr(n, ia, ja, a, kmax=50, frac=0.95)
+    x1 = single.apply(rhs)
+    ko, fo, ib, jb, bb = oracle.band_extract(n, ia, ja, a, 50, 0.95)
+    assert (k1, f1) == (ko, fo)
+
+    def fn(r, sp):
+        sp.set_option("partitions", Pl)
+        r0, r1 = cuts[r], cuts[r + 1]
+        k, f = sp.setup_csr_dist(n, r0, ia[r0:r1 + 1] - ia[r0], ja[ia[r0]:ia[r1]], a[ia[r0]:ia[r1]], kmax=50, frac=0.95)
+        x = sp.apply(torch.from_numpy(rhs[r0:r1].copy()).cuda())
+        torch.cuda.synchronize()
+        return k, f, x.cpu().numpy()
+
+    res = _run_ranks(spike, G, fn)
+    assert all(r[0] == k1 for r in res) and len({r[1] for r in res}) == 1      # same k, bitwise the same fraction on all ranks
+    assert abs(res[0][1] - f1) <= 1e-12                  # another summation order of ~7e5 terms than the sequential rule
+    x = np.concatenate([r[2] for r in res])
+    assert np.linalg.norm(x - x1) <= 1e-12 * np.linalg.norm(x1)
+    band = oracle.csr_to_band(n, ib, jb, bb, ko)
+    ref = oracle.Spike(band, G * Pl).apply(rhs, 1)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)

@@ -127,3 +127,41 @@ def test_gmres_manufactured_solution(oracle):
     assert ok and it <= 2 and np.linalg.norm(x - u) <= 1e-6 * np.sqrt(N)
     x0, it0, rn0, hist0, ok0 = oracle.gmres(band, b, sp, variant=0)
     assert ok0 and it0 > it and np.linalg.norm(x0 - u) <= 1e-2 * np.sqrt(N)
+
+
+def test_distributed_band_rule_pieces_equal_the_sequential_rule(oracle):
+    """spike_csr_band_weights (one rank's part of the weights, row-block layout of matbanded.c:36) + spike_band_rule: the
+    parts of any row split, added in rank order, reproduce the k of the sequential rule (and its fraction to rounding)."""
+    import ctypes as C
+    import scipy.sparse as sps
+    from conftest import _ensure_built
+    _ensure_built()
+    import spike_petsc_amd as S
+    L = S.lib()
+    rng = np.random.default_rng(3)
+    n = 3000
+    A = sps.random(n, n, density=0.004, random_state=5, format="csr") + sps.diags([rng.uniform(1, 2, n)], [0])
+    A = sps.csr_matrix(A)
+    A.sort_indices()
+    ia, ja, a = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+    for kmax, frac in ((50, 0.95), (7, 0.999), (300, 0.5)):
+        k0, f0 = S.csr_band_k(n, ia, ja, a, kmax, frac)
+        ko, fo, *_ = oracle.band_extract(n, ia, ja, a, kmax, frac)
+        assert (k0, f0) == (ko, fo)
+        for cuts in ([0, n], [0, 1024, n], [0, 64, 1984, 2048, n]):
+            w = np.zeros(kmax)
+            na = 0.0
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                wp = np.zeros(kmax)
+                nap = C.c_double(0)
+                lia = np.ascontiguousarray(ia[r0:r1 + 1] - ia[r0])
+                lja = np.ascontiguousarray(ja[ia[r0]:ia[r1]])
+                la = np.ascontiguousarray(a[ia[r0]:ia[r1]])
+                assert L.spike_csr_band_weights(n, r0, r1 - r0, lia.ctypes.data_as(S.iptr), lja.ctypes.data_as(S.iptr),
+                                                la.ctypes.data_as(S.dptr), kmax, wp.ctypes.data_as(S.dptr), C.byref(nap)) == 0
+                w += wp
+                na += nap.value
+            k = C.c_int(0)
+            f = C.c_double(0)
+            assert L.spike_band_rule(n, w.ctypes.data_as(S.dptr), na, kmax, frac, C.byref(k), C.byref(f)) == 0
+            assert k.value == k0 and abs(f.value - f0) <= 1e-14

@@ -763,8 +763,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     mark("boost threshold");
     // LU (scratch copy), then pack into sweep tiles
     double *dLU = nullptr;
-    HIPCHK(tmp.alloc(&dLU, (size_t)nd * n));
-    HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
+    const size_t lu_blk = lu_blocks_doubles(n, K);   // K > 32: block-band scratch (dense 16 x 16 tiles), made in one transposing pass
+    HIPCHK(tmp.alloc(&dLU, lu_blk ? lu_blk : (size_t)nd * n));
+    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, h->dA, h->ldA, dLU, st));
+    else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
     HIPCHK(launch_factor(dLU, n, K, h->dChains, P, boost, dNb, st));

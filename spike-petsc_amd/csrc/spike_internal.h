@@ -77,6 +77,10 @@ hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepA
 // launch -- two vectors ride on one pass over the factors for free; beyond that the block step is no longer memory-bound.
 constexpr int SWEEP_MULTI_NR = 2;
 hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st);
+// K > 32: the LU scratch of launch_factor / launch_pack is the BLOCK-BAND layout (dense 16 x 16 tiles, see spike_kernels.hip)
+// made by launch_band_to_blocks from the diagonal-major band; lu_blocks_doubles = its size (0: diagonal-major scratch)
+size_t lu_blocks_doubles(int64_t n, int K);
+hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st);
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st);
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,

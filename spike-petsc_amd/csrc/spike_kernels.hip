@@ -724,6 +724,92 @@ __global__ __launch_bounds__(256) void k_factor(double *lu, int64_t ld, int K, c
 // f64 MFMA lane maps (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // C/D: col = l&15, row = (l>>4) + 4*reg.
 // ------------------------------------------------------------------------------------------
+// ---- LU scratch layouts --------------------------------------------------------------------------------------------
+// The factorisation works on 16 x 16 tiles.  Reading them out of the DIAGONAL-major band is a gather: the 16 entries of
+// a tile row lie on 16 different diagonals, N*8 bytes apart -- every lane of a tile load touches its own cache line,
+// and a block step of the K = 128 factorisation moves 2 x 4352 such 8-byte accesses (measured round 1: 22 us per block
+// step against 1.7 us of MFMA work).  For K > 32 the scratch is therefore the BLOCK-BAND layout: per 16-row block the
+// NTL = 2*KB + 1 tiles (rb, rb-KB .. rb+KB) as dense row-major 16 x 16 squares, 2 KiB contiguous each --
+//     T[((rbg * NTL) + (cb - rb + KB)) * 256 + row * 16 + col],  rbg = global row block.
+// A tile load is then 4 x 512 contiguous bytes per wave, a finished tile goes back as one 2-KiB store, and the packing
+// kernel finds the K entries of a row next to each other.  k_band_to_blocks makes it from the kept band in one
+// transposing pass (it replaces the plain scratch copy).  ntl = 0 selects the diagonal-major scratch (K <= 32).
+struct LuView {
+    double *p;
+    int64_t ld;    // diagonal-major: row count of a diagonal
+    int K, KB, ntl;
+    __device__ __forceinline__ int64_t bb(int64_t rbg, int rb_rel_slot, int row, int col) const
+    {
+        return ((rbg * ntl) + rb_rel_slot) * 256 + row * 16 + col;
+    }
+};
+
+// element (r, c) of the chain that starts at local row rs (multiple of 64); r, c chain-local, |c - r| <= 16*KB assumed for
+// the block-band layout when slot is in range
+__device__ __forceinline__ double lu_get(const LuView &v, int64_t rs, int r, int c)
+{
+    if (v.ntl == 0) {
+        const int d = c - r + v.K;
+        if (d < 0 || d > 2 * v.K) return 0.0;
+        return v.p[(int64_t)d * v.ld + rs + r];
+    }
+    const int rb = r >> 4, cb = c >> 4, slot = cb - rb + v.KB;
+    if (slot < 0 || slot >= v.ntl) return 0.0;
+    return v.p[v.bb((rs >> 4) + rb, slot, r & 15, c & 15)];
+}
+__device__ __forceinline__ void lu_put(const LuView &v, int64_t rs, int r, int c, double val)
+{
+    if (v.ntl == 0) {
+        const int d = c - r + v.K;
+        if (d >= 0 && d <= 2 * v.K) v.p[(int64_t)d * v.ld + rs + r] = val;
+        return;
+    }
+    const int rb = r >> 4, cb = c >> 4, slot = cb - rb + v.KB;
+    if (slot >= 0 && slot < v.ntl) v.p[v.bb((rs >> 4) + rb, slot, r & 15, c & 15)] = val;
+}
+
+// diagonal-major band -> block-band scratch; one workgroup per 16-row block, the strip transposed through LDS
+__global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB, const double *band, int64_t ld, double *T)
+{
+    extern __shared__ double strip[];   // 16 x (W + 1), W = 16 * NTL
+    const int NTL = 2 * KB + 1, W = 16 * NTL, LDW = W + 1;
+    const int64_t rbg = blockIdx.x;
+    const int t = threadIdx.x, row = t & 15, sub = t >> 4;
+    for (int q = t; q < 16 * LDW; q += 256) strip[q] = 0.0;
+    __syncthreads();
+    const int64_t i = rbg * 16 + row;
+    if (i < n)
+        for (int d = sub; d <= 2 * K; d += 16)   // 16 lanes = 16 consecutive rows of one diagonal (128 contiguous bytes)
+            strip[row * LDW + row + d - K + 16 * KB] = band[(int64_t)d * ld + i];
+    __syncthreads();
+    double *out = T + rbg * NTL * 256;
+    for (int j = 0; j < NTL; ++j) out[j * 256 + t] = strip[(t >> 4) * LDW + 16 * j + (t & 15)];
+}
+
+// window width (in 16 x 16 tiles) of the blocked factorisation kernels = half-width of the block-band scratch
+static inline int lu_kb(int K) { return K <= 64 ? 4 : (K <= 128 ? 8 : 16); }
+
+hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int KB = lu_kb(K), NTL = 2 * KB + 1;
+    const size_t shm = (size_t)16 * (16 * NTL + 1) * sizeof(double);
+    if (shm > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_to_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_band_to_blocks, dim3((unsigned)((n + 15) / 16)), dim3(256), shm, st, n, K, KB, band, ld, T);
+    return hipGetLastError();
+}
+
+// doubles of the block-band scratch for n local rows (0 when the diagonal-major scratch is used)
+size_t lu_blocks_doubles(int64_t n, int K)
+{
+    if (K <= 32) return 0;
+    const int KB = lu_kb(K);
+    return (size_t)((n + 15) / 16) * (size_t)(2 * KB + 1) * 256;
+}
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int LDT = 17;            // LDS tile row stride (doubles), padded against bank conflicts
 constexpr int TS = 16 * LDT;       // LDS tile size
@@ -733,8 +819,8 @@ constexpr int TS = 16 * LDT;       // LDS tile size
 // Called by all threads after the panel tiles are in LDS and a barrier; returns after the write-back was issued
 // (the caller's next barrier orders it).
 template <int KB, int NT>
-__device__ __forceinline__ void panel_phase(double *Pd, double *Pc, double *Pr, int s, int np, int64_t rs, int K, int64_t ld,
-                                            double *lu, double boost, unsigned long long &nb, int tid, int lane, int w)
+__device__ __forceinline__ void panel_phase(double *Pd, double *Pc, double *Pr, int s, int np, int64_t rs, const LuView &lv,
+                                            double boost, unsigned long long &nb, int tid, int lane, int w)
 {
     // ---- 16 x 16 diagonal block: LU without pivoting, pivot boosting (one wave, in LDS)
     if (w == 0) {
@@ -802,13 +888,12 @@ __device__ __forceinline__ void panel_phase(double *Pd, double *Pc, double *Pr, 
         else if (tile <= KB) { rb = s + tile; cb = s; T = Pc + (tile - 1) * TS; }
         else { rb = s; cb = s + tile - KB; T = Pr + (tile - KB - 1) * TS; }
         const int r = 16 * rb + row, c = 16 * cb + col;
-        const int d = c - r + K;
-        if (r < np && c < np && d >= 0 && d <= 2 * K) lu[(int64_t)d * ld + rs + r] = T[row * LDT + col];
+        if (r < np && c < np) lu_put(lv, rs, r, c, T[row * LDT + col]);   // block-band: 256 consecutive threads = one 2-KiB tile
     }
 }
 
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void k_factor_mfma(double *lu, int64_t ld, int K, const ChainDesc *chains, double boost,
+__global__ __launch_bounds__(NW * 64) void k_factor_mfma(LuView lv, const ChainDesc *chains, double boost,
                                                          unsigned long long *nboost)
 {
     constexpr int RPW = KB / NW;
@@ -826,9 +911,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(double *lu, int64_t ld,
     auto ldA = [&](int rb, int cb, int row, int col) -> double {
         const int r = 16 * rb + row, c = 16 * cb + col;  // partition-local
         if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;  // identity padding past the partition end
-        const int d = c - r + K;
-        if (d < 0 || d > 2 * K) return 0.0;
-        return lu[(int64_t)d * ld + rs + r];
+        return lu_get(lv, rs, r, c);
     };
     auto load_tile = [&](v4d &t, int rb, int cb) {
 #pragma unroll
@@ -872,7 +955,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(double *lu, int64_t ld,
             Pr[(KB - 1) * TS + row * LDT + col] = ldA(s, s + KB, row, col);
         }
         __syncthreads();
-        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, K, ld, lu, boost, nb, tid, lane, w);
+        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, lv, boost, nb, tid, lane, w);
         // ---- trailing update: tile(s+I, s+J) -= L21[I] * U12[J]   (4 x v_mfma_f64_16x16x4_f64 per tile)
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
@@ -899,7 +982,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(double *lu, int64_t ld,
 // Same algorithm with the trailing window left in global memory (L2 / Infinity Cache resident) and updated in place:
 // used when the K x K window (512 KiB at K = 256) does not fit the register file of one CU.
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int64_t ld, int K, const ChainDesc *chains,
+__global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(LuView lv, const ChainDesc *chains,
                                                                  double boost, unsigned long long *nboost)
 {
     constexpr int NT = NW * 64;
@@ -915,9 +998,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int
     auto ldA = [&](int rb, int cb, int row, int col) -> double {
         const int r = 16 * rb + row, c = 16 * cb + col;
         if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;
-        const int d = c - r + K;
-        if (d < 0 || d > 2 * K) return 0.0;
-        return lu[(int64_t)d * ld + rs + r];
+        return lu_get(lv, rs, r, c);
     };
     for (int s = 0; s < nblk; ++s) {
         for (int t = tid; t < (2 * KB + 1) * 256; t += NT) {
@@ -927,7 +1008,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int
             else Pr[(tile - KB - 1) * TS + row * LDT + col] = ldA(s, s + tile - KB, row, col);
         }
         __syncthreads();
-        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, K, ld, lu, boost, nb, tid, lane, w);
+        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, lv, boost, nb, tid, lane, w);
         for (int t = w; t < KB * KB; t += NW) {
             const int I = t / KB + 1, J = t % KB + 1;
             if (16 * (s + I) >= np || 16 * (s + J) >= np) continue;
@@ -941,8 +1022,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 16 * (s + I) + (lane >> 4) + 4 * q, c = 16 * (s + J) + (lane & 15);
-                const int d = c - r + K;
-                if (r < np && c < np && d >= 0 && d <= 2 * K) lu[(int64_t)d * ld + rs + r] = acc[q];
+                if (r < np && c < np) lu_put(lv, rs, r, c, acc[q]);
             }
         }
         __syncthreads();
@@ -951,7 +1031,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(double *lu, int
 }
 
 template <int KB, int NW>
-static hipError_t launch_factor_mfma_inplace_t(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains,
+static hipError_t launch_factor_mfma_inplace_t(const LuView &lv, const ChainDesc *chains, int nchains,
                                                double boost, unsigned long long *nboost, hipStream_t st)
 {
     const size_t shm = (size_t)(2 * KB + 1) * TS * sizeof(double);
@@ -960,12 +1040,12 @@ static hipError_t launch_factor_mfma_inplace_t(double *lu, int64_t ld, int K, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_factor_mfma_inplace<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lu, ld, K, chains, boost, nboost);
+    hipLaunchKernelGGL((k_factor_mfma_inplace<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lv, chains, boost, nboost);
     return hipGetLastError();
 }
 
 template <int KB, int NW>
-static hipError_t launch_factor_mfma_t(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
+static hipError_t launch_factor_mfma_t(const LuView &lv, const ChainDesc *chains, int nchains, double boost,
                                        unsigned long long *nboost, hipStream_t st)
 {
     const size_t shm = (size_t)(2 * KB + 1) * TS * sizeof(double);
@@ -974,23 +1054,27 @@ static hipError_t launch_factor_mfma_t(double *lu, int64_t ld, int K, const Chai
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_factor_mfma<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lu, ld, K, chains, boost, nboost);
+    hipLaunchKernelGGL((k_factor_mfma<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lv, chains, boost, nboost);
     return hipGetLastError();
 }
 
 hipError_t launch_factor_generic(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                                  unsigned long long *nboost, hipStream_t st);
 
+// lu: diagonal-major scratch (ld = n) for K <= 32, block-band scratch (launch_band_to_blocks) for K > 32
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st)
 {
     if (nchains <= 0) return hipSuccess;
     if (K <= 8) return launch_factor_generic(lu, ld, K, chains, nchains, boost, nboost, st);
-    if (K <= 16) return launch_factor_mfma_t<1, 1>(lu, ld, K, chains, nchains, boost, nboost, st);
-    if (K <= 32) return launch_factor_mfma_t<2, 2>(lu, ld, K, chains, nchains, boost, nboost, st);
-    if (K <= 64) return launch_factor_mfma_t<4, 4>(lu, ld, K, chains, nchains, boost, nboost, st);
-    if (K <= 128) return launch_factor_mfma_t<8, 4>(lu, ld, K, chains, nchains, boost, nboost, st);
-    return launch_factor_mfma_inplace_t<16, 8>(lu, ld, K, chains, nchains, boost, nboost, st);
+    LuView lv;
+    lv.p = lu; lv.ld = ld; lv.K = K; lv.KB = (K + 15) / 16; lv.ntl = K > 32 ? 2 * lv.KB + 1 : 0;
+    if (K <= 16) return launch_factor_mfma_t<1, 1>(lv, chains, nchains, boost, nboost, st);
+    if (K <= 32) return launch_factor_mfma_t<2, 2>(lv, chains, nchains, boost, nboost, st);
+    lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;   // block-band scratch: as wide as the kernels' window
+    if (K <= 64) return launch_factor_mfma_t<4, 4>(lv, chains, nchains, boost, nboost, st);
+    if (K <= 128) return launch_factor_mfma_t<8, 4>(lv, chains, nchains, boost, nboost, st);
+    return launch_factor_mfma_inplace_t<16, 8>(lv, chains, nchains, boost, nboost, st);
 }
 
 hipError_t launch_factor_generic(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
@@ -1099,7 +1183,7 @@ __global__ __launch_bounds__(64) void k_pack(int DPW, int NW, const double *lu, 
 //  multiplier reads get hoisted above the serial FMA chain and spill ~7000 registers; measured 107 ms.)
 // ------------------------------------------------------------------------------------------
 template <bool UPPER>
-__device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const double *lu, int64_t ld, int K,
+__device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const LuView &lv, int K,
                                             const ChainDesc &cd, int sb, double *T, double *dinv)
 {
     constexpr int R = 64;
@@ -1110,8 +1194,9 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const d
     const bool rowok = r < rows_here;
     const int Kn = K < R - 1 ? K : R - 1;
     double di = 1.0;
+    const int rl = sb * R + (rowok ? r : 0);                   // chain-local row of this lane (clamped)
     if (UPPER && rowok) {
-        di = 1.0 / lu[(int64_t)K * ld + i0 + r];
+        di = 1.0 / lu_get(lv, cd.row0, rl, rl);
         dinv[i0 + r] = di;
     }
     // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER).
@@ -1121,8 +1206,8 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const d
     WAVE_LDS_FENCE();
     for (int d = 1; d <= Kn; ++d) {
         if (d <= lane && rowok) {
-            if (!UPPER) Ms[lane * R + lane - d] = lu[(int64_t)(K - d) * ld + i0 + r];
-            else if (r + d < rows_here) Ms[lane * R + lane - d] = lu[(int64_t)(K + d) * ld + i0 + r] * di;
+            if (!UPPER) Ms[lane * R + lane - d] = lu_get(lv, cd.row0, rl, rl - d);
+            else if (r + d < rows_here) Ms[lane * R + lane - d] = lu_get(lv, cd.row0, rl, rl + d) * di;
         }
     }
     WAVE_LDS_FENCE();
@@ -1150,13 +1235,12 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const d
     constexpr int NLD = 16;   // DPW = 32 for every R = 64 configuration
     (void)DPW;
     d2 *T2 = reinterpret_cast<d2 *>(T);
-    const int64_t rr = i0 + (rowok ? r : 0);
     auto val = [&](int d) -> double {
         const bool near = d <= lane;
         const bool far_ok = !near && d <= K && rowok &&
                             (UPPER ? ((int64_t)sb * R + r + d < cd.nrows) : ((int64_t)sb * R + r - d >= 0));
         const int dd = far_ok ? d : 0;
-        const double g = lu[(int64_t)(UPPER ? K + dd : K - dd) * ld + rr];
+        const double g = lu_get(lv, cd.row0, rl, UPPER ? rl + dd : rl - dd);
         const double l = Ms[lane * R + (near ? lane - d : 0)];
         return near ? -l : (far_ok ? (UPPER ? g * di : g) : 0.0);
     };
@@ -1173,7 +1257,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const d
     }
 }
 
-__global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, const double *lu, int64_t ld, int K, const ChainDesc *chains,
+__global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, LuView lv, int K, const ChainDesc *chains,
                                                const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
 {
     __shared__ double Ms[64 * 64];
@@ -1182,9 +1266,9 @@ __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, const double *lu
     if (sb >= cd.nsteps) return;
     const GroupDesc gd = groups[p];
     const int64_t tdbl = (int64_t)NW * DPW * 64;
-    pack64_side<false>(Ms, DPW, NW, lu, ld, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
+    pack64_side<false>(Ms, DPW, NW, lv, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
     WAVE_LDS_FENCE();
-    pack64_side<true>(Ms, DPW, NW, lu, ld, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
+    pack64_side<true>(Ms, DPW, NW, lv, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
 }
 
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
@@ -1198,7 +1282,12 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
     case 8: hipLaunchKernelGGL((k_pack<8>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 16: hipLaunchKernelGGL((k_pack<16>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 32: hipLaunchKernelGGL((k_pack<32>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
-    case 64: hipLaunchKernelGGL(k_pack64, grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
+    case 64: {
+        LuView lv;   // K > 32: the scratch is block-band (launch_band_to_blocks / launch_factor)
+        lv.p = const_cast<double *>(lu); lv.ld = ld; lv.K = K; lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;
+        hipLaunchKernelGGL(k_pack64, grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lv, K, chains, groups, Lt, Ut, dinv);
+        break;
+    }
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -196,6 +196,27 @@ int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches);
  * non-temporal access shape as the sweeps), i.e. the read ceiling this device delivers                     */
 int spike_measure_read_bw(spike_handle h, int reps, double *gbps);
 
+/* ---- device half of the Fiedler ordering (reference slot MatGetOrdering_Fiedler, src/petsc_mat_fiedler.c:11-58) -------------
+ * The ordering itself is host code (libspike_petsc_host: spike_fiedler_order_ex); its floating-point part, the LOBPCG
+ * refinement of a multilevel level, can run here.  These calls hold one level's vectors on the device (ids 0 x, 1 Lx, 2 w,
+ * 3 Lw, 4 p, 5 Lp, 6 the constant 1) and execute the statements of fiedler.c:refine_core() in the same IEEE operations and
+ * the same reduction order as the host implementation: the resulting permutation is bit-identical.                     */
+typedef struct spike_fd_ctx spike_fd_ctx;
+int spike_device_count(void); /* HIP devices visible (0: none; never an error) */
+int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *adj, const double *w, const double *deg,
+                    const double *x0, spike_fd_ctx **out);
+int spike_fd_destroy(spike_fd_ctx *c);
+int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *ib, double *sums); /* nd <= 6 dot products */
+int spike_fd_lap(spike_fd_ctx *c, int src, int dst);                                    /* v[dst] = L v[src]   */
+int spike_fd_resid(spike_fd_ctx *c, double rho, double *rn2);                           /* w = Lx - rho x      */
+int spike_fd_precond(spike_fd_ctx *c, double *sum);                                     /* w /= deg            */
+int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
+int spike_fd_axpy(spike_fd_ctx *c, double a, int x, int y, int x2, int y2);
+int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
+int spike_fd_update(spike_fd_ctx *c, double c0, double c1, double c2, int havep);
+int spike_fd_fill_alternating(spike_fd_ctx *c);
+int spike_fd_download_x(spike_fd_ctx *c, double *x);
+
 #ifdef __cplusplus
 }
 #endif

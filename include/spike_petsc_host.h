@@ -165,6 +165,10 @@ int spike_mc64_job5(int64_t n, const int64_t *colptr, const int64_t *rowind, con
                     double *u, double *v, int64_t *num);
 int spike_awbm(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, double *sr, double *sc);
 int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec);
+/* use_device != 0 and a HIP device present: the LOBPCG refinement of the large multilevel levels runs on the GPU
+ * (libspike_mi355: spike_fd_*), with a bit-identical permutation */
+int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec,
+                           int use_device);
 int spike_rcm_order(int64_t n, const int64_t *ia, const int64_t *ja, int64_t *order);
 int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
                             int64_t *bandwidth);

@@ -21,12 +21,24 @@
  *              src/spectralPartition.c:336-338), ties by index.  Output order[k] = old index of the vertex placed at
  *              position k (the "new -> old" convention of a PETSc IS, i.e. what petsc_mat_fiedler.c:49 builds).
  *
- * All arithmetic is sequential fp64 in a fixed order => the permutation is reproducible bit for bit.
+ *  6. arithmetic: IEEE fp64, one operation at a time (no fused multiply-add: this file is compiled with
+ *     -ffp-contract=off), every sum of the LOBPCG refinement (dot products, the mean deflate() removes, the residual
+ *     norm) in ONE fixed REDUCTION ORDER: chunks of 1024 consecutive indices; inside a chunk 256 slots,
+ *     slot t = ((v[t] + v[t+256]) + v[t+512]) + v[t+768] (absent elements = +0.0), the binary tree s[t] += s[t+o] for
+ *     o = 128 ... 1, and the chunk sums added in chunk order.  That order is what a 256-thread workgroup computes
+ *     naturally, so the SAME refinement runs on the device (csrc/spike_fiedler.hip, levels of >= 12288 vertices when a
+ *     device is present and use_device is set) with bit-identical results: refine_core() below is the only copy of the
+ *     iteration, driven through a small table of vector operations that has a host and a device implementation.
+ *
+ * => the permutation is reproducible bit for bit, on the host alone or with the device doing the vector work
+ *    (tests/test_host_gpu.py::test_fiedler_device_equals_host_bit_for_bit).
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef int64_t I;
 
@@ -48,9 +60,27 @@ static void lap_mult(const graph_t *g, const double *x, double *y)
     }
 }
 
-static double dot(I n, const double *a, const double *b) { double s = 0; for (I i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
-static void deflate(I n, double *x) { double m = 0; for (I i = 0; i < n; ++i) m += x[i]; m /= (double)n; for (I i = 0; i < n; ++i) x[i] -= m; }
-static double normalize(I n, double *x) { double s = sqrt(dot(n, x, x)); if (s > 0) for (I i = 0; i < n; ++i) x[i] /= s; return s; }
+/* THE reduction order of the spec (header, item 6): sum_i a[i]*b[i]; b == NULL means b = 1 */
+static double dot(I n, const double *a, const double *b)
+{
+    double total = 0.0;
+    for (I c0 = 0; c0 < n; c0 += 1024) {
+        double sl[256];
+        for (int t = 0; t < 256; ++t) {
+            double v = 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const I i = c0 + t + 256 * q;
+                const double pr = (i < n) ? (b ? a[i] * b[i] : a[i] * 1.0) : 0.0;
+                v = (q == 0) ? pr : v + pr;
+            }
+            sl[t] = v;
+        }
+        for (int o = 128; o > 0; o >>= 1)
+            for (int t = 0; t < o; ++t) sl[t] += sl[t + o];
+        total += sl[0];
+    }
+    return total;
+}
 
 /* cyclic Jacobi for a dense symmetric matrix (n <= ~64): eigenvalues in ev, eigenvectors in columns of V */
 static void jacobi_eig(int n, double *A, double *V, double *ev)
@@ -149,60 +179,184 @@ static void eig3(int m, double G[3][3], double c[3], double *lam)
     *lam = ev[b];
 }
 
-/* single-vector LOBPCG for the smallest eigenpair of L restricted to the complement of the constant vector */
-static void refine(const graph_t *g, double *x, int maxit)
+/* ---- the vectors of one refinement and the operations the iteration is written in ------------------------------------------
+ * ids: 0 x, 1 Lx, 2 w, 3 Lw, 4 p, 5 Lp, 6 the constant 1.  Two implementations: host arrays (below) and the device
+ * (spike_fd_* of libspike_mi355.so); both execute the same IEEE operations in the same order. */
+#define FD_DEVICE_MIN 12288   /* smaller levels are launch-latency bound on the device (~0.2 ms per iteration whatever n; the host needs ~17 ns per vertex and iteration); the result is the same either way */
+static int g_last_its = 0;   /* SPIKE_FIEDLER_TRACE only */
+typedef struct spike_fd_ctx spike_fd_ctx;
+int spike_device_count(void);
+int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *adj, const double *w, const double *deg, const double *x0, spike_fd_ctx **out);
+int spike_fd_destroy(spike_fd_ctx *c);
+int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *ib, double *sums);
+int spike_fd_lap(spike_fd_ctx *c, int src, int dst);
+int spike_fd_resid(spike_fd_ctx *c, double rho, double *rn2);
+int spike_fd_precond(spike_fd_ctx *c, double *sum);
+int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
+int spike_fd_axpy(spike_fd_ctx *c, double a, int x, int y, int x2, int y2);
+int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
+int spike_fd_update(spike_fd_ctx *c, double c0, double c1, double c2, int havep);
+int spike_fd_fill_alternating(spike_fd_ctx *c);
+int spike_fd_download_x(spike_fd_ctx *c, double *x);
+
+typedef struct {
+    const graph_t *g;
+    I n;
+    double *v[6];        /* host backend: x, Lx, w, Lw, p, Lp */
+    spike_fd_ctx *dev;   /* device backend (NULL: host) */
+    int err;
+} vecs_t;
+
+static void op_dots(vecs_t *V, int nd, const int *ia, const int *ib, double *sums)
 {
-    const I n = g->n;
-    double *Lx = (double *)malloc(sizeof(double) * (size_t)n * 6);
-    double *w = Lx + n, *Lw = w + n, *p = Lw + n, *Lp = p + n, *t = Lp + n;
-    double dmax = 0;
-    for (I i = 0; i < n; ++i) if (g->deg[i] > dmax) dmax = g->deg[i];
-    deflate(n, x);
-    if (normalize(n, x) == 0.0) { for (I i = 0; i < n; ++i) x[i] = (double)(i % 2 ? 1 : -1); deflate(n, x); normalize(n, x); }
-    lap_mult(g, x, Lx);
+    if (V->dev) { if (spike_fd_dots(V->dev, nd, ia, ib, sums)) V->err = 1; return; }
+    for (int j = 0; j < nd; ++j) sums[j] = dot(V->n, V->v[ia[j]], ib[j] == 6 ? NULL : V->v[ib[j]]);
+}
+static double op_dot(vecs_t *V, int a, int b) { double s = 0.0; op_dots(V, 1, &a, &b, &s); return s; }
+static void op_lap(vecs_t *V, int src, int dst)
+{
+    if (V->dev) { if (spike_fd_lap(V->dev, src, dst)) V->err = 1; return; }
+    lap_mult(V->g, V->v[src], V->v[dst]);
+}
+static double op_resid(vecs_t *V, double rho)   /* w = Lx - rho x; returns sum w_i^2 */
+{
+    double rn2 = 0.0;
+    if (V->dev) { if (spike_fd_resid(V->dev, rho, &rn2)) V->err = 1; return rn2; }
+    for (I i = 0; i < V->n; ++i) V->v[2][i] = V->v[1][i] - rho * V->v[0][i];
+    return dot(V->n, V->v[2], V->v[2]);
+}
+static double op_precond(vecs_t *V)   /* w_i /= deg_i (1 for isolated vertices); returns sum w_i */
+{
+    double s = 0.0;
+    if (V->dev) { if (spike_fd_precond(V->dev, &s)) V->err = 1; return s; }
+    for (I i = 0; i < V->n; ++i) V->v[2][i] /= (V->g->deg[i] > 0 ? V->g->deg[i] : 1.0);
+    return dot(V->n, V->v[2], NULL);
+}
+static void op_shift(vecs_t *V, int a, double m)
+{
+    if (V->dev) { if (spike_fd_shift(V->dev, a, m)) V->err = 1; return; }
+    for (I i = 0; i < V->n; ++i) V->v[a][i] -= m;
+}
+static void op_axpy(vecs_t *V, double a, int x, int y, int x2, int y2)   /* y -= a x [, y2 -= a x2] */
+{
+    if (V->dev) { if (spike_fd_axpy(V->dev, a, x, y, x2, y2)) V->err = 1; return; }
+    for (I i = 0; i < V->n; ++i) V->v[y][i] -= a * V->v[x][i];
+    if (y2 >= 0) for (I i = 0; i < V->n; ++i) V->v[y2][i] -= a * V->v[x2][i];
+}
+static void op_div(vecs_t *V, double s, int y, int y2)
+{
+    if (V->dev) { if (spike_fd_div(V->dev, s, y, y2)) V->err = 1; return; }
+    for (I i = 0; i < V->n; ++i) V->v[y][i] /= s;
+    if (y2 >= 0) for (I i = 0; i < V->n; ++i) V->v[y2][i] /= s;
+}
+static void op_update(vecs_t *V, double c0, double c1, double c2, int havep)
+{
+    if (V->dev) { if (spike_fd_update(V->dev, c0, c1, c2, havep)) V->err = 1; return; }
+    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *Lw = V->v[3], *p = V->v[4], *Lp = V->v[5];
+    for (I i = 0; i < V->n; ++i) {
+        const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
+        const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
+        x[i] = c0 * x[i] + pn;
+        Lx[i] = c0 * Lx[i] + Lpn;
+        p[i] = pn; Lp[i] = Lpn;
+    }
+}
+static void op_fill_alternating(vecs_t *V)
+{
+    if (V->dev) { if (spike_fd_fill_alternating(V->dev)) V->err = 1; return; }
+    for (I i = 0; i < V->n; ++i) V->v[0][i] = (double)(i % 2 ? 1 : -1);
+}
+static void op_deflate(vecs_t *V, int a) { const double m = op_dot(V, a, 6) / (double)V->n; op_shift(V, a, m); }
+static double op_normalize(vecs_t *V, int a) { const double s = sqrt(op_dot(V, a, a)); if (s > 0) op_div(V, s, a, -1); return s; }
+
+/* single-vector LOBPCG for the smallest eigenpair of L restricted to the complement of the constant vector: THE iteration,
+   the same statements whichever side holds the vectors */
+static void refine_core(vecs_t *V, double dmax, int maxit)
+{
+    op_deflate(V, 0);
+    if (op_normalize(V, 0) == 0.0) { op_fill_alternating(V); op_deflate(V, 0); op_normalize(V, 0); }
+    op_lap(V, 0, 1);
     int havep = 0;
-    for (int it = 0; it < maxit; ++it) {
-        const double rho = dot(n, x, Lx);
-        double rn = 0;
-        for (I i = 0; i < n; ++i) { const double r = Lx[i] - rho * x[i]; w[i] = r; rn += r * r; }
-        if (sqrt(rn) <= 1e-9 * dmax) break;
-        for (I i = 0; i < n; ++i) w[i] /= (g->deg[i] > 0 ? g->deg[i] : 1.0);
-        deflate(n, w);
+    g_last_its = 0;
+    for (int it = 0; it < maxit && !V->err; ++it) {
+        g_last_its = it + 1;
+        const double rho = op_dot(V, 0, 1);
+        const double rn2 = op_resid(V, rho);
+        if (sqrt(rn2) <= 1e-9 * dmax) break;
+        { const double m = op_precond(V) / (double)V->n; op_shift(V, 2, m); }   /* w /= deg, constant vector deflated */
         /* orthogonalise w against x (and p), normalise */
-        double a = dot(n, w, x);
-        for (I i = 0; i < n; ++i) w[i] -= a * x[i];
+        double a;
         if (havep) {
-            a = dot(n, p, x);
-            for (I i = 0; i < n; ++i) { p[i] -= a * x[i]; Lp[i] -= a * Lx[i]; }
-            const double pn = sqrt(dot(n, p, p));
-            if (pn > 1e-300) { for (I i = 0; i < n; ++i) { p[i] /= pn; Lp[i] /= pn; } }
+            const int ia[2] = {2, 4}, ib[2] = {0, 0};
+            double d2[2];
+            op_dots(V, 2, ia, ib, d2);             /* w.x and p.x (independent of each other) */
+            op_axpy(V, d2[0], 0, 2, -1, -1);
+            op_axpy(V, d2[1], 0, 4, 1, 5);         /* p -= a x, Lp -= a Lx */
+            const double pn = sqrt(op_dot(V, 4, 4));
+            if (pn > 1e-300) op_div(V, pn, 4, 5);
             else havep = 0;
+        } else {
+            a = op_dot(V, 2, 0);
+            op_axpy(V, a, 0, 2, -1, -1);
         }
-        if (havep) { a = dot(n, w, p); for (I i = 0; i < n; ++i) w[i] -= a * p[i]; }
-        if (normalize(n, w) < 1e-300) break;
-        lap_mult(g, w, Lw);
+        if (havep) { a = op_dot(V, 2, 4); op_axpy(V, a, 4, 2, -1, -1); }
+        if (op_normalize(V, 2) < 1e-300) break;
+        op_lap(V, 2, 3);
         const int m = havep ? 3 : 2;
-        double G[3][3], c[3], lam;
-        const double *S[3] = {x, w, p}, *LS[3] = {Lx, Lw, Lp};
-        for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) G[i][j] = G[j][i] = dot(n, S[i], LS[j]);
+        double G[3][3], c[3], lam, d6[6];
+        if (m == 3) {
+            const int ia[6] = {0, 0, 0, 2, 2, 4}, ib[6] = {1, 3, 5, 3, 5, 5};
+            op_dots(V, 6, ia, ib, d6);
+            G[0][0] = d6[0]; G[0][1] = G[1][0] = d6[1]; G[0][2] = G[2][0] = d6[2];
+            G[1][1] = d6[3]; G[1][2] = G[2][1] = d6[4]; G[2][2] = d6[5];
+        } else {
+            const int ia[3] = {0, 0, 2}, ib[3] = {1, 3, 3};
+            op_dots(V, 3, ia, ib, d6);
+            G[0][0] = d6[0]; G[0][1] = G[1][0] = d6[1]; G[1][1] = d6[2];
+        }
         eig3(m, G, c, &lam);
         if (c[0] < 0) for (int i = 0; i < m; ++i) c[i] = -c[i];
-        for (I i = 0; i < n; ++i) {
-            const double pn = c[1] * w[i] + (havep ? c[2] * p[i] : 0.0);
-            const double Lpn = c[1] * Lw[i] + (havep ? c[2] * Lp[i] : 0.0);
-            t[i] = c[0] * x[i] + pn;
-            Lx[i] = c[0] * Lx[i] + Lpn;
-            p[i] = pn; Lp[i] = Lpn;
-        }
-        memcpy(x, t, sizeof(double) * (size_t)n);
+        op_update(V, c[0], c[1], havep ? c[2] : 0.0, havep);
         havep = 1;
-        const double xn = sqrt(dot(n, x, x));
-        for (I i = 0; i < n; ++i) { x[i] /= xn; Lx[i] /= xn; }
+        const double xn = sqrt(op_dot(V, 0, 0));
+        op_div(V, xn, 0, 1);
     }
-    free(Lx);
 }
 
-static void fiedler_vector(const graph_t *g, double *x, int level)
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static void refine_impl(const graph_t *g, double *x, int maxit, int use_device);
+static void refine(const graph_t *g, double *x, int maxit, int use_device)
+{
+    if (!getenv("SPIKE_FIEDLER_TRACE")) { refine_impl(g, x, maxit, use_device); return; }
+    const double t0 = now_s();
+    refine_impl(g, x, maxit, use_device);
+    fprintf(stderr, "[fiedler] level n=%lld  %s  iterations=%d  %.3f ms\n", (long long)g->n,
+            (use_device && g->n >= FD_DEVICE_MIN) ? "device" : "host", g_last_its, 1e3 * (now_s() - t0));
+}
+
+static void refine_impl(const graph_t *g, double *x, int maxit, int use_device)
+{
+    const I n = g->n;
+    double dmax = 0;
+    for (I i = 0; i < n; ++i) if (g->deg[i] > dmax) dmax = g->deg[i];
+    vecs_t V;
+    memset(&V, 0, sizeof V);
+    V.g = g; V.n = n;
+    if (use_device && n >= FD_DEVICE_MIN && spike_fd_create(n, g->xadj, g->adj, g->w, g->deg, x, &V.dev) == 0) {
+        refine_core(&V, dmax, maxit);
+        if (!V.err && spike_fd_download_x(V.dev, x)) V.err = 1;
+        spike_fd_destroy(V.dev);
+        if (!V.err) return;
+        V.dev = NULL; V.err = 0;   /* device trouble: the host computes the same thing (x was not touched) */
+    }
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n * 5);
+    V.v[0] = x; V.v[1] = buf; V.v[2] = buf + n; V.v[3] = buf + 2 * n; V.v[4] = buf + 3 * n; V.v[5] = buf + 4 * n;
+    refine_core(&V, dmax, maxit);
+    free(buf);
+}
+
+static void fiedler_vector(const graph_t *g, double *x, int level, int use_device)
 {
     const I n = g->n;
     if (n <= 64 || level >= 40) {
@@ -222,7 +376,7 @@ static void fiedler_vector(const graph_t *g, double *x, int level)
         } else {
             for (I i = 0; i < n; ++i) x[i] = (double)i - 0.5 * (double)(n - 1);
         }
-        refine(g, x, 300);
+        refine(g, x, 300, use_device);
         return;
     }
     graph_t c;
@@ -230,13 +384,13 @@ static void fiedler_vector(const graph_t *g, double *x, int level)
     I *map = coarsen(g, &c);
     if (c.n > (9 * n) / 10) { /* matching stalls (e.g. star graphs): stop coarsening here */
         for (I i = 0; i < n; ++i) x[i] = (double)i - 0.5 * (double)(n - 1);
-        refine(g, x, 1000);
+        refine(g, x, 1000, use_device);
     } else {
         double *xc = (double *)malloc(sizeof(double) * (size_t)c.n);
-        fiedler_vector(&c, xc, level + 1);
+        fiedler_vector(&c, xc, level + 1, use_device);
         for (I i = 0; i < n; ++i) x[i] = xc[map[i]];
         free(xc);
-        refine(g, x, 300);
+        refine(g, x, 300, use_device);
     }
     free(map);
     graph_free(&c);
@@ -255,8 +409,20 @@ static int cmp_desc(const void *a, const void *b)
  * n, ia, ja, a : 0-based CSR.  order[k] = old index at new position k.  vec (optional, length n) receives the
  * per-component Fiedler vectors.  Returns 0 or -1.
  */
+int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec,
+                           int use_device);
+
+/* host only */
 int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec)
 {
+    return spike_fiedler_order_ex(n, ia, ja, a, order, vec, 0);
+}
+
+/* use_device != 0: the LOBPCG refinement of levels with >= 12288 vertices runs on the GPU (bit-identical result) */
+int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec,
+                           int use_device)
+{
+    if (use_device && spike_device_count() <= 0) use_device = 0;
     if (n <= 0 || !ia || !ja || !a || !order) return -1;
     const int weighted = (ia[n] > 0 && a[0] > 0.0);
     const double tol = 1e-12;
@@ -368,7 +534,7 @@ int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const d
             sg.deg[t] = g.deg[v];
         }
         double *x = (double *)malloc(sizeof(double) * (size_t)nc);
-        fiedler_vector(&sg, x, 0);
+        fiedler_vector(&sg, x, 0, use_device);
         /* sign: largest magnitude entry positive */
         I im = 0;
         for (I t = 1; t < nc; ++t) if (fabs(x[t]) > fabs(x[im])) im = t;

@@ -357,7 +357,10 @@ PetscErrorCode MatGetOrdering_Fiedler(Mat A, MatOrderingType type, IS *row, IS *
     (void)type;
     const PetscInt n = A->n;
     PetscInt *ord = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
-    if (spike_fiedler_order(n, A->ia, A->ja, A->a, ord, NULL)) { free(ord); return seterr(PETSC_ERR_LIB, "Fiedler ordering failed"); }
+    /* -mat_fiedler_device 0|1 (default 1): the LOBPCG refinement on the GPU when one is present; same permutation either way */
+    int usedev = 1;
+    { char v[16]; if (opt_str(NULL, "mat_fiedler_device", v, sizeof v)) usedev = atoi(v) != 0; }
+    if (spike_fiedler_order_ex(n, A->ia, A->ja, A->a, ord, NULL, usedev)) { free(ord); return seterr(PETSC_ERR_LIB, "Fiedler ordering failed"); }
     PetscErrorCode e = ISCreateGeneral(n, ord, row);
     free(ord);
     if (e) return e;

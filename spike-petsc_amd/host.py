@@ -27,7 +27,7 @@ HOST_SYMBOLS = [
     "PCBandedGetInfo", "PCGetSpikeHandle", "KSPRegister", "KSPCreate", "KSPSetType", "KSPSetOptionsPrefix",
     "KSPAppendOptionsPrefix", "KSPSetOperators", "KSPGetPC", "KSPSetTolerances", "KSPSetFromOptions", "KSPSetUp",
     "KSPSolve", "KSPGetConvergedReason", "KSPGetIterationNumber", "KSPGetResidualNorm", "KSPView", "KSPDestroy",
-    "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order",
+    "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order", "spike_fiedler_order_ex",
     "spike_profile_bandwidth", "spike_awbm", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
 ]
 
@@ -103,6 +103,7 @@ def lib():
     L.MatViewBinary.argtypes = [vp, C.c_char_p]
     L.spike_rcm_order.argtypes = [i64, i64p, i64p, i64p]
     L.spike_fiedler_order.argtypes = [i64, i64p, i64p, dp, i64p, dp]
+    L.spike_fiedler_order_ex.argtypes = [i64, i64p, i64p, dp, i64p, dp, C.c_int]
     L.spike_profile_bandwidth.argtypes = [i64, i64p, i64p, i64p, i64p, i64p]
     _L = L
     return L
@@ -221,12 +222,13 @@ def rcm_order(n, ia, ja):
     return order
 
 
-def fiedler_order(n, ia, ja, a):
+def fiedler_order(n, ia, ja, a, use_device=False):
+    """use_device: the LOBPCG refinement of the large levels on the GPU (bit-identical permutation)"""
     ia, ja, a = _i(ia), _i(ja), _d(a)
     order = np.zeros(n, dtype=np.int64)
     vec = np.zeros(n)
-    if lib().spike_fiedler_order(n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp),
-                                 order.ctypes.data_as(i64p), vec.ctypes.data_as(dp)):
+    if lib().spike_fiedler_order_ex(n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp),
+                                    order.ctypes.data_as(i64p), vec.ctypes.data_as(dp), int(bool(use_device))):
         raise HostError("spike_fiedler_order failed")
     return order, vec
 

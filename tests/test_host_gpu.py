@@ -155,3 +155,25 @@ def test_c_driver_testbed2_runs_the_reference_pipeline(H, tmp_path):
     its = int([l for l in out.stdout.splitlines() if l.startswith("Iterations:")][0].split()[1])
     assert err <= 1e-3 * np.sqrt(n) and its <= 60
     assert "reordering type = wbm" in out.stdout and "Banded: k =" in out.stdout and "SPIKE (MI355X)" in out.stdout
+
+
+@pytest.mark.parametrize("n,seed", [(30000, 11), (321821, 5)])
+def test_fiedler_device_equals_host_bit_for_bit(H, n, seed):
+    """SURVEY 8f-4 / north star "bit-exact Fiedler permutation": the LOBPCG refinement on the GPU (spike_fd_*, levels of
+    >= 12288 vertices) and on the host execute the same IEEE operations in the same (published) reduction order, so the
+    Fiedler vector and the permutation are identical to the last bit -- on the circuit-like stand-in at the driver-run size
+    and at the size of ASIC_320k (BASELINE config 4; the real file is not available offline)."""
+    import time
+    A = circuit_like(n, seed=seed)
+    S = sp.csr_matrix(A + A.T)       # the ordering symmetrises anyway; this keeps the input a plain CSR
+    S.sort_indices()
+    t0 = time.perf_counter()
+    od, vd = H.fiedler_order(n, S.indptr, S.indices, S.data, use_device=True)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oh, vh = H.fiedler_order(n, S.indptr, S.indices, S.data, use_device=False)
+    t_host = time.perf_counter() - t0
+    print("fiedler n=%d: device-assisted %.3f s, host %.3f s" % (n, t_dev, t_host))
+    assert np.array_equal(od, oh)
+    assert np.array_equal(vd.view(np.uint64), vh.view(np.uint64))          # the vectors agree bit for bit, not just the order
+    assert sorted(od.tolist()) == list(range(n))

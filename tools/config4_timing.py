@@ -10,7 +10,8 @@ t=time.time(); A=circuit_like(n,seed=7,band=24); print("gen %.1fs nnz %d"%(time.
 t=time.time(); perm,u,v,num=H.mc64_job5(n,A.indptr,A.indices,A.data); print("mc64 job5 %.2fs num %d"%(time.time()-t,num))
 B=A[perm]  # row permutation (mat_wbm_rows)
 B=B.tocsr(); B.sort_indices()
-t=time.time(); o,vec=H.fiedler_order(n,B.indptr,B.indices,B.data); tf=time.time()-t
+t=time.time(); o,vec=H.fiedler_order(n,B.indptr,B.indices,B.data,use_device=True); tf=time.time()-t
+t=time.time(); oh,vech=H.fiedler_order(n,B.indptr,B.indices,B.data,use_device=False); print("fiedler host-only %.2fs, identical to device-assisted: %s"%(time.time()-t, bool(np.array_equal(o,oh))))
 print("fiedler %.2fs profile/bw"%tf, H.profile_bandwidth(n,B.indptr,B.indices), H.profile_bandwidth(n,B.indptr,B.indices,o))
 t=time.time(); o2=H.rcm_order(n,B.indptr,B.indices); print("rcm %.2fs"%(time.time()-t), H.profile_bandwidth(n,B.indptr,B.indices,o2))
 for second in ("fiedler","rcm"):

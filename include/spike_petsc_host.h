@@ -170,6 +170,12 @@ int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const d
 int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec,
                            int use_device);
 int spike_rcm_order(int64_t n, const int64_t *ia, const int64_t *ja, int64_t *order);
+/* Fiedler bisection + reverse Cuthill-McKee on each half's diagonal block, composed -- the per-half reordering prototyped
+ * in src/spectralPartition.c:326-417.  pos_size: rows in the positive half; halves_bw[4] (optional): bandwidth of the
+ * positive / negative block before and after its own reordering.  Ordering name in the registry: "fiedler_halves". */
+int spike_fiedler_halves_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order,
+                               int64_t *pos_size, int64_t *halves_bw, int use_device);
+PetscErrorCode MatGetOrdering_FiedlerHalves(Mat A, MatOrderingType type, IS *row, IS *col);
 int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
                             int64_t *bandwidth);
 

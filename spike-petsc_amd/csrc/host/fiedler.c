@@ -551,6 +551,67 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
     return 0;
 }
 
+/*
+ * Fiedler bisection + per-half second-stage ordering, the scheme the reference prototypes in
+ * /root/reference/src/spectralPartition.c:326-417: order by the Fiedler vector (descending, :336-338), cut where the
+ * vector changes sign (positive entries first, :331-333, 340-343), reorder the diagonal block of each half on its own
+ * with a second ordering (there: -mat_ordering_type through MatGetOrdering on the two MatGetSubMatrix blocks, :369-381;
+ * here: reverse Cuthill-McKee, the second stage of src/HOWTO:2 and src/testbed.c:236-284) and compose the two
+ * permutations (:383-404).  halves_bw (optional, 4 entries) = bandwidth of the positive / negative block before and
+ * after its reordering (what :377-382 prints).  order[k] = old index at new position k.
+ */
+int spike_rcm_order(int64_t n, const int64_t *ia, const int64_t *ja, int64_t *order);
+int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
+                            int64_t *bandwidth);
+
+int spike_fiedler_halves_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order,
+                               int64_t *pos_size, int64_t *halves_bw, int use_device)
+{
+    if (n <= 0 || !ia || !ja || !a || !order) return -1;
+    double *vec = (double *)malloc(sizeof(double) * (size_t)n);
+    I *of = (I *)malloc(sizeof(I) * (size_t)n), *newpos = (I *)malloc(sizeof(I) * (size_t)n);
+    if (!vec || !of || !newpos || spike_fiedler_order_ex(n, ia, ja, a, of, vec, use_device)) { free(vec); free(of); free(newpos); return -1; }
+    /* the reference counts strictly positive entries over the WHOLE vector (:331-333); with several components the
+       per-component vectors are concatenated, so the cut is taken where the ordered sequence first becomes <= 0 */
+    I np = 0;
+    for (I k = 0; k < n; ++k) if (vec[of[k]] > 0.0) ++np;
+    /* positions: positives first in Fiedler order, then the rest in Fiedler order (stable partition of `of`) */
+    I *seq = (I *)malloc(sizeof(I) * (size_t)n);
+    { I a0 = 0, b0 = np; for (I k = 0; k < n; ++k) { const I v = of[k]; if (vec[v] > 0.0) seq[a0++] = v; else seq[b0++] = v; } }
+    for (I k = 0; k < n; ++k) newpos[seq[k]] = k;
+    int rc = 0;
+    for (int half = 0; half < 2 && !rc; ++half) {
+        const I off = half == 0 ? 0 : np, m = half == 0 ? np : n - np;
+        if (m <= 0) { if (halves_bw) { halves_bw[2 * half] = 0; halves_bw[2 * half + 1] = 0; } continue; }
+        /* diagonal block of the permuted matrix: rows/columns = positions [off, off+m), local numbering */
+        I *sia = (I *)calloc((size_t)m + 1, sizeof(I));
+        for (I t = 0; t < m; ++t) {
+            const I v = seq[off + t];
+            for (I k = ia[v]; k < ia[v + 1]; ++k) { const I q = newpos[ja[k]]; if (q >= off && q < off + m) ++sia[t + 1]; }
+        }
+        for (I t = 0; t < m; ++t) sia[t + 1] += sia[t];
+        I *sja = (I *)malloc(sizeof(I) * (size_t)(sia[m] > 0 ? sia[m] : 1));
+        for (I t = 0; t < m; ++t) {
+            const I v = seq[off + t];
+            I w = sia[t];
+            for (I k = ia[v]; k < ia[v + 1]; ++k) { const I q = newpos[ja[k]]; if (q >= off && q < off + m) sja[w++] = q - off; }
+        }
+        I *so = (I *)malloc(sizeof(I) * (size_t)m);
+        if (spike_rcm_order(m, sia, sja, so)) rc = -1;
+        else {
+            if (halves_bw) {
+                spike_profile_bandwidth(m, sia, sja, NULL, NULL, &halves_bw[2 * half]);
+                spike_profile_bandwidth(m, sia, sja, so, NULL, &halves_bw[2 * half + 1]);
+            }
+            for (I t = 0; t < m; ++t) order[off + t] = seq[off + so[t]];   /* compose, :388-404 */
+        }
+        free(sia); free(sja); free(so);
+    }
+    if (pos_size) *pos_size = np;
+    free(vec); free(of); free(newpos); free(seq);
+    return rc;
+}
+
 /* profile and bandwidth of the symmetrised pattern under order[] (what petsc_mat_fiedler.c:51-52 prints) */
 int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
                             int64_t *bandwidth)

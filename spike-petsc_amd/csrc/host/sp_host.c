@@ -324,6 +324,26 @@ PetscErrorCode MatGetOrdering_WBM(Mat A, MatOrderingType type, IS *row, IS *col)
     free(perm);
     return e;
 }
+/* the per-half scheme of src/spectralPartition.c:326-417 (Fiedler cut, each half reordered on its own, composed); prints
+   the reference's two "Reduced ... bandwidth" lines (:377-382) */
+PetscErrorCode MatGetOrdering_FiedlerHalves(Mat A, MatOrderingType type, IS *row, IS *col)
+{
+    (void)type;
+    const PetscInt n = A->n;
+    PetscInt *ord = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
+    int usedev = 1;
+    { char v[16]; if (opt_str(NULL, "mat_fiedler_device", v, sizeof v)) usedev = atoi(v) != 0; }
+    int64_t np = 0, bw[4] = {0, 0, 0, 0};
+    if (spike_fiedler_halves_order(n, A->ia, A->ja, A->a, ord, &np, bw, usedev)) { free(ord); return seterr(PETSC_ERR_LIB, "Fiedler per-half ordering failed"); }
+    printf("Reduced positive bandwidth from %lld to %lld\n", (long long)bw[0], (long long)bw[1]);
+    printf("Reduced negative bandwidth from %lld to %lld\n", (long long)bw[2], (long long)bw[3]);
+    PetscErrorCode e = ISCreateGeneral(n, ord, row);
+    free(ord);
+    if (e) return e;
+    ++(*row)->refct;
+    *col = *row;
+    return 0;
+}
 /* PETSc's built-in "rcm", used by the reference as second-stage ordering (src/HOWTO:2, src/testbed.c:236-284) */
 PetscErrorCode MatGetOrdering_RCM(Mat A, MatOrderingType type, IS *row, IS *col)
 {
@@ -887,6 +907,7 @@ PetscErrorCode SpikePetscRegisterAll(void)
     CHK(MatOrderingRegister("wbm", MatGetOrdering_WBM));         /* testbed2.c:66 */
     CHK(MatOrderingRegister("awbm", MatGetOrdering_AWBM));       /* :67 */
     CHK(MatOrderingRegister("fiedler", MatGetOrdering_Fiedler)); /* :68 */
+    CHK(MatOrderingRegister("fiedler_halves", MatGetOrdering_FiedlerHalves)); /* spectralPartition.c:369-417 as an ordering */
     CHK(PCRegister(PCNONE, PCCreate_None));
     CHK(PCRegister(PCSPIKE, PCCreate_Spike));
     CHK(PCRegister(PCBANDED, PCCreate_Banded)); /* :70 */

@@ -27,7 +27,7 @@ HOST_SYMBOLS = [
     "PCBandedGetInfo", "PCGetSpikeHandle", "KSPRegister", "KSPCreate", "KSPSetType", "KSPSetOptionsPrefix",
     "KSPAppendOptionsPrefix", "KSPSetOperators", "KSPGetPC", "KSPSetTolerances", "KSPSetFromOptions", "KSPSetUp",
     "KSPSolve", "KSPGetConvergedReason", "KSPGetIterationNumber", "KSPGetResidualNorm", "KSPView", "KSPDestroy",
-    "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order", "spike_fiedler_order_ex",
+    "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order", "spike_fiedler_order_ex", "spike_fiedler_halves_order", "MatGetOrdering_FiedlerHalves",
     "spike_profile_bandwidth", "spike_awbm", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
 ]
 
@@ -104,6 +104,7 @@ def lib():
     L.spike_rcm_order.argtypes = [i64, i64p, i64p, i64p]
     L.spike_fiedler_order.argtypes = [i64, i64p, i64p, dp, i64p, dp]
     L.spike_fiedler_order_ex.argtypes = [i64, i64p, i64p, dp, i64p, dp, C.c_int]
+    L.spike_fiedler_halves_order.argtypes = [i64, i64p, i64p, dp, i64p, i64p, i64p, C.c_int]
     L.spike_profile_bandwidth.argtypes = [i64, i64p, i64p, i64p, i64p, i64p]
     _L = L
     return L
@@ -231,6 +232,18 @@ def fiedler_order(n, ia, ja, a, use_device=False):
                                     order.ctypes.data_as(i64p), vec.ctypes.data_as(dp), int(bool(use_device))):
         raise HostError("spike_fiedler_order failed")
     return order, vec
+
+
+def fiedler_halves_order(n, ia, ja, a, use_device=False):
+    """Fiedler cut + RCM on each half (src/spectralPartition.c:326-417): (order, positive-half size, [bw pos before, after, neg before, after])"""
+    ia, ja, a = _i(ia), _i(ja), _d(a)
+    order = np.zeros(n, dtype=np.int64)
+    bw = np.zeros(4, dtype=np.int64)
+    npos = i64(0)
+    if lib().spike_fiedler_halves_order(n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp),
+                                        order.ctypes.data_as(i64p), C.byref(npos), bw.ctypes.data_as(i64p), int(bool(use_device))):
+        raise HostError("spike_fiedler_halves_order failed")
+    return order, npos.value, bw
 
 
 def profile_bandwidth(n, ia, ja, order=None):

@@ -182,6 +182,30 @@ def test_fiedler_recovers_hidden_band_and_is_deterministic(H):
     assert abs(v1.sum()) <= 1e-8 and lam * (1 - 1e-9) <= rho <= 1.25 * lam
 
 
+def test_fiedler_halves_is_the_reference_prototype(H):
+    """Per-half reordering (src/spectralPartition.c:326-417): Fiedler cut where the vector changes sign, RCM on each half's
+    diagonal block, the two permutations composed.  Checked against a direct restatement of those steps."""
+    n, K = 3000, 5
+    rng = np.random.default_rng(2)
+    B = sp.diags([rng.uniform(0.2, 1, n - abs(d)) for d in range(-K, K + 1)], list(range(-K, K + 1))).tocsr()
+    q = rng.permutation(n)
+    A = B[q][:, q].tocsr(); A.sort_indices()
+    order, npos, bw = H.fiedler_halves_order(n, A.indptr, A.indices, A.data)
+    assert sorted(order.tolist()) == list(range(n))
+    of, vec = H.fiedler_order(n, A.indptr, A.indices, A.data)
+    assert npos == int((vec > 0).sum()) and 0 < npos < n
+    seq = np.concatenate([[v for v in of if vec[v] > 0], [v for v in of if not vec[v] > 0]]).astype(np.int64)   # :340-343
+    assert set(order[:npos].tolist()) == set(seq[:npos].tolist())                                     # halves keep their members
+    for off, m, k in ((0, npos, 0), (npos, n - npos, 2)):
+        S = A[seq[off:off + m]][:, seq[off:off + m]].tocsr(); S.sort_indices()                         # MatGetSubMatrix, :373-374
+        so = H.rcm_order(m, S.indptr, S.indices)                                                       # MatGetOrdering, :377-378
+        assert np.array_equal(order[off:off + m], seq[off + so])                                       # composition, :388-404
+        assert bw[k] == H.profile_bandwidth(m, S.indptr, S.indices)[1] and bw[k + 1] == H.profile_bandwidth(m, S.indptr, S.indices, so)[1]
+        assert bw[k + 1] <= bw[k]
+    # (the scheme reorders the halves independently: it narrows each diagonal block, not the coupling between the halves)
+    assert bw[1] <= 4 * K and bw[3] <= 4 * K
+
+
 def test_fiedler_small_exact_and_components(H):
     # path graph on 9 vertices: Fiedler vector is monotone -> the order is the path (up to direction)
     n = 9

@@ -829,24 +829,73 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(hipMemsetAsync(dStat, 0, 4 * sizeof(double), st));
         int nmin = h->chains[0].nrows, nmax = h->chains[0].nrows;
         for (int p = 1; p < P; ++p) { nmin = std::min<int>(nmin, h->chains[p].nrows); nmax = std::max<int>(nmax, h->chains[p].nrows); }
+        int nsmin = h->chains[0].nsteps;
+        for (int p = 1; p < P; ++p) nsmin = std::min<int>(nsmin, h->chains[p].nsteps);
+        // sub-chains: the top / bottom nb row blocks of every chain (one chain per workgroup configurations).  A spike
+        // lives next to its interface, so the solves that produce it need only those blocks: exact on the forward sweep,
+        // and the backward sweep starts where the solution is already below the drop level.
+        auto build_sub = [&](int nb, SubChains &top, SubChains &bot) -> int {
+            const int R = cfg.R;
+            std::vector<ChainDesc> ct(P), cb(P);
+            std::vector<GroupDesc> gtF(P), gtB(P), gbF(P), gbB(P);
+            for (int p = 0; p < P; ++p) {
+                const ChainDesc &c = h->chains[p];
+                const GroupDesc &g = h->groups[p];
+                const int skip = c.nsteps - nb;
+                ct[p].row0 = c.row0; ct[p].nrows = std::min<int>(c.nrows, nb * R); ct[p].nsteps = nb;
+                gtF[p] = g; gtF[p].maxsteps = nb;
+                gtB[p] = g; gtB[p].maxsteps = nb; gtB[p].tile0 = g.tile0 + skip;
+                cb[p].row0 = c.row0 + (int64_t)skip * R; cb[p].nrows = c.nrows - skip * R; cb[p].nsteps = nb;
+                gbF[p] = g; gbF[p].maxsteps = nb; gbF[p].tile0 = g.tile0 + skip;
+                gbB[p] = g; gbB[p].maxsteps = nb;
+            }
+            ChainDesc *dC[2] = {nullptr, nullptr};
+            GroupDesc *dG[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int i = 0; i < 2; ++i) HIPCHK(tmp.alloc(&dC[i], (size_t)P));
+            for (int i = 0; i < 4; ++i) HIPCHK(tmp.alloc(&dG[i], (size_t)P));
+            HIPCHK(hipMemcpyAsync(dC[0], ct.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dC[1], cb.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dG[0], gtF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dG[1], gtB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dG[2], gbF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dG[3], gbB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));   // the host vectors go out of scope
+            top.chains = dC[0]; top.groupsF = dG[0]; top.groupsB = dG[1];
+            bot.chains = dC[1]; bot.groupsF = dG[2]; bot.groupsB = dG[3];
+            return SPIKE_OK;
+        };
         int extent = 0;
         if (h->spike_storage || h->S > 1) {
-            for (int which = 0; which < 2; ++which) {
-                HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
-                for (int t = 0; t < 2; ++t) {
-                    const int col = t == 0 ? 0 : K - 1;
-                    if (t == 1 && K == 1) break;
-                    HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
-                    if ((rc = run_pass(h, rhs, sol, false))) return rc;
-                    HIPCHK(launch_absmax_diag(sol, n, 0, n, dStat + 2, st));
-                    double amax = 0.0;
-                    HIPCHK(hipMemcpyAsync(&amax, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
-                    HIPCHK(hipStreamSynchronize(st));
-                    HIPCHK(launch_spike_extent(sol, h->dChains, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
+            // First on the 24 K rows next to the interfaces (spikes of the dominant systems truncated SPIKE is meant for
+            // die within ~10 K rows: four passes over an eighth of the factors instead of four full passes); if the
+            // spike has not died inside that depth, the probe is repeated on the whole chains.
+            const int nbp = (24 * K + 64 + cfg.R - 1) / cfg.R + 1;
+            bool shallow = cfg.CPW() == 1 && nbp < nsmin;
+            SubChains pTop, pBot;
+            if (shallow && (rc = build_sub(nbp, pTop, pBot))) return rc;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                HIPCHK(hipMemsetAsync(dStat + 3, 0, sizeof(double), st));
+                for (int which = 0; which < 2; ++which) {
+                    HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = t == 0 ? 0 : K - 1;
+                        if (t == 1 && K == 1) break;
+                        HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
+                        if (shallow) HIPCHK(hipMemsetAsync(sol, 0, sizeof(double) * n, st));   // rows outside the probed depth read as zero
+                        if ((rc = run_pass(h, rhs, sol, false, shallow ? (which == 0 ? &pTop : &pBot) : nullptr))) return rc;
+                        HIPCHK(launch_absmax_diag(sol, n, 0, n, dStat + 2, st));
+                        double amax = 0.0;
+                        HIPCHK(hipMemcpyAsync(&amax, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                        HIPCHK(launch_spike_extent(sol, h->dChains, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
+                    }
                 }
+                HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                // the spike must have died well inside the probed depth (one block of margin beyond the storage margin)
+                if (!shallow || (int64_t)(extent * 1.06) + K + 2 * cfg.R <= (int64_t)(nbp - 1) * cfg.R) break;
+                shallow = false;
             }
-            HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
         }
         mark("spike reach probe");
         if (h->S > 1) {
@@ -879,47 +928,19 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         // the top nb blocks of every chain for W, the bottom nb blocks for V (exact on the forward sweep, and the
         // backward sweep starts where the solution is already below the drop level).
         SubChains subTop, subBot;
-        ChainDesc *dSubC[2] = {nullptr, nullptr};
-        GroupDesc *dSubG[4] = {nullptr, nullptr, nullptr, nullptr};
         bool partial = false;
         if (m > 0 && cfg.CPW() == 1) {
-            const int R = cfg.R;
-            int nsmin = h->chains[0].nsteps;
-            for (int p = 1; p < P; ++p) nsmin = std::min<int>(nsmin, h->chains[p].nsteps);
-            const int nb = (m + K + R - 1) / R + 1;
+            const int nb = (m + K + cfg.R - 1) / cfg.R + 1;
             if (nb < nsmin) {
                 partial = true;
-                std::vector<ChainDesc> ct(P), cb(P);
-                std::vector<GroupDesc> gtF(P), gtB(P), gbF(P), gbB(P);
-                for (int p = 0; p < P; ++p) {
-                    const ChainDesc &c = h->chains[p];
-                    const GroupDesc &g = h->groups[p];
-                    const int skip = c.nsteps - nb;
-                    ct[p].row0 = c.row0; ct[p].nrows = std::min<int>(c.nrows, nb * R); ct[p].nsteps = nb;
-                    gtF[p] = g; gtF[p].maxsteps = nb;
-                    gtB[p] = g; gtB[p].maxsteps = nb; gtB[p].tile0 = g.tile0 + skip;
-                    cb[p].row0 = c.row0 + (int64_t)skip * R; cb[p].nrows = c.nrows - skip * R; cb[p].nsteps = nb;
-                    gbF[p] = g; gbF[p].maxsteps = nb; gbF[p].tile0 = g.tile0 + skip;
-                    gbB[p] = g; gbB[p].maxsteps = nb;
-                }
-                for (int i = 0; i < 2; ++i) HIPCHK(tmp.alloc(&dSubC[i], (size_t)P));
-                for (int i = 0; i < 4; ++i) HIPCHK(tmp.alloc(&dSubG[i], (size_t)P));
-                HIPCHK(hipMemcpyAsync(dSubC[0], ct.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(dSubC[1], cb.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(dSubG[0], gtF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(dSubG[1], gtB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(dSubG[2], gbF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(dSubG[3], gbB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-                HIPCHK(hipStreamSynchronize(st));
-                subTop.chains = dSubC[0]; subTop.groupsF = dSubG[0]; subTop.groupsB = dSubG[1];
-                subBot.chains = dSubC[1]; subBot.groupsF = dSubG[2]; subBot.groupsB = dSubG[3];
+                if ((rc = build_sub(nb, subTop, subBot))) return rc;
             }
         }
         mark("sub-chain descriptors");
-        // The 2K spike columns are solved SWEEP_MULTI_NR at a time (k_sweep_multi: a factor tile is read once for the
+        // The 2K spike columns are solved sweep_multi_nr(cfg) at a time (k_sweep_multi: a factor tile is read once for the
         // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
         const bool batched = cfg.R == 64 && !cfg.scan;
-        const int NRB = batched ? SWEEP_MULTI_NR : 1;
+        const int NRB = batched ? sweep_multi_nr(cfg) : 1;
         double *rhsM = rhs, *solM = sol, *midM = h->dY;
         if (batched) {
             HIPCHK(tmp.alloc(&rhsM, (size_t)NRB * n));

@@ -72,10 +72,11 @@ bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf);
 
 // launchers (spike_kernels.hip)
 hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepArgs &a, hipStream_t st, int tag = 0);
-// setup: SWEEP_MULTI_NR right-hand sides per launch (R = 64 configurations), vector q at in/out + q*ldr.
-// Measured at N = 4M, K = 128 (partial chains of 26 row blocks): 1 rhs 145 us, 2 rhs 137 us, 3 rhs 300 us, 4 rhs 380 us per
-// launch -- two vectors ride on one pass over the factors for free; beyond that the block step is no longer memory-bound.
-constexpr int SWEEP_MULTI_NR = 2;
+// setup: sweep_multi_nr(cfg) right-hand sides per launch (R = 64 configurations), vector q at in/out + q*ldr.
+// Round 1 (32 diagonals per wave): 1 rhs 145 us, 2 rhs 137 us, 3 rhs 300 us, 4 rhs 380 us per launch at N = 4M, K = 128 on
+// partial chains of 26 row blocks -- beyond two vectors the kernel needed > 256 VGPRs.  Round 2: 16 diagonals per wave
+// (the tile layout does not care), 167 VGPRs with FOUR vectors.
+int sweep_multi_nr(const SweepCfg &cfg);   // right-hand sides per launch of launch_sweep_multi for this configuration
 hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st);
 // K > 32: the LU scratch of launch_factor / launch_pack is the BLOCK-BAND layout (dense 16 x 16 tiles, see spike_kernels.hip)
 // made by launch_band_to_blocks from the diagonal-major band; lu_blocks_doubles = its size (0: diagonal-major scratch)

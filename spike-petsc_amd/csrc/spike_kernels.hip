@@ -319,14 +319,14 @@ hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepA
 // two workgroup barriers of a block step are shared by the NR vectors.  R = 64, DPW = 32 only (one chain per workgroup);
 // right-hand side q lives at in + q*ldr / out + q*ldr.  No corrections (setup never needs them).
 // ------------------------------------------------------------------------------------------
-template <int NW, bool REV, int NR>
+template <int DPW, int NW, bool REV, int NR>
 __global__ __launch_bounds__(NW * 64) void k_sweep_multi(SweepArgs a, int64_t ldr)
 {
-    constexpr int R = 64, DPW = 32;
+    constexpr int R = 64;
     constexpr int KP = DPW * NW;
     constexpr int NLD = DPW / 2;
     constexpr int WS = next_pow2(KP + R);
-    constexpr int NWB = 2 < NW ? 2 : NW;   // (R - 2) / DPW + 1 = 2 waves own in-block entries
+    constexpr int NWB = ((R - 2) / DPW + 1) < NW ? ((R - 2) / DPW + 1) : NW;   // waves that own in-block entries
     constexpr int64_t TILE2 = (int64_t)NW * NLD * 64;
 
     __shared__ double W[NR][2 * WS];
@@ -437,13 +437,20 @@ __global__ __launch_bounds__(NW * 64) void k_sweep_multi(SweepArgs a, int64_t ld
     }
 }
 
-template <int NW>
+template <int DPW, int NW, int NR>
 static hipError_t launch_sweep_multi_t(bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st)
 {
-    if (rev) hipLaunchKernelGGL((k_sweep_multi<NW, true, SWEEP_MULTI_NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
-    else hipLaunchKernelGGL((k_sweep_multi<NW, false, SWEEP_MULTI_NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
+    if (rev) hipLaunchKernelGGL((k_sweep_multi<DPW, NW, true, NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
+    else hipLaunchKernelGGL((k_sweep_multi<DPW, NW, false, NR>), dim3(nchains), dim3(NW * 64), 0, st, a, ldr);
     return hipGetLastError();
 }
+
+// right-hand sides per launch for this configuration (setup asks before it sizes its buffers).  The tile layout does not
+// depend on how the diagonals are dealt to waves, so the batched solves use 16 diagonals per wave: half the tile
+// registers per wave leave room for FOUR right-hand sides per pass over the factors (with 32 diagonals per wave a third
+// vector already pushed the kernel past 256 VGPRs: round 1).  K > 128 would need more than 8 such waves at 128 VGPRs
+// each and keeps two vectors.
+int sweep_multi_nr(const SweepCfg &cfg) { return (cfg.R == 64 && !cfg.scan && cfg.NW <= 4) ? 4 : 2; }
 
 // one chain per workgroup (groups[p] describes chain p): configurations with R = 64 only
 hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st)
@@ -451,11 +458,11 @@ hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const 
     if (nchains <= 0) return hipSuccess;
     if (cfg.R != 64 || cfg.scan) return hipErrorInvalidValue;
     switch (cfg.NW) {
-    case 2: return launch_sweep_multi_t<2>(rev, nchains, a, ldr, st);
-    case 3: return launch_sweep_multi_t<3>(rev, nchains, a, ldr, st);
-    case 4: return launch_sweep_multi_t<4>(rev, nchains, a, ldr, st);
-    case 6: return launch_sweep_multi_t<6>(rev, nchains, a, ldr, st);
-    case 8: return launch_sweep_multi_t<8>(rev, nchains, a, ldr, st);
+    case 2: return launch_sweep_multi_t<16, 4, 4>(rev, nchains, a, ldr, st);
+    case 3: return launch_sweep_multi_t<16, 6, 4>(rev, nchains, a, ldr, st);
+    case 4: return launch_sweep_multi_t<16, 8, 4>(rev, nchains, a, ldr, st);
+    case 6: return launch_sweep_multi_t<32, 6, 2>(rev, nchains, a, ldr, st);
+    case 8: return launch_sweep_multi_t<32, 8, 2>(rev, nchains, a, ldr, st);
     }
     return hipErrorInvalidValue;
 }

@@ -1189,6 +1189,102 @@ __global__ __launch_bounds__(64) void k_pack(int DPW, int NW, const double *lu, 
 // (A variant with the inverse's column in 64 registers and a fully unrolled substitution was tried: the 2016 independent
 //  multiplier reads get hoisted above the serial FMA chain and spill ~7000 registers; measured 107 ms.)
 // ------------------------------------------------------------------------------------------
+constexpr int PACK_LDM = 65;   // LDS row stride of the 64 x 64 block in k_pack64
+
+// In-place inverse of a 64 x 64 UNIT LOWER triangular matrix held row-major in LDS (only the strictly lower triangle is
+// read and written; the unit diagonal is implicit), by ONE wave:
+//   A. the four 16 x 16 diagonal tiles by forward substitution, lane = (tile, column), the column in 16 registers;
+//   B. the six off-diagonal tiles from  M X = I  in block form,  X_ij = -E_i * sum_{k=j}^{i-1} M_ik X_kj  (E_i = the inverted
+//      diagonal tile, X_jj = E_j), as 16 x 16 x 16 products on v_mfma_f64_16x16x4: the A operands (M_ik, E_i) come from LDS,
+//      the B operands are the D registers of earlier products -- the C/D layout of this instruction (row = (l>>4) + 4r,
+//      column = l&15) IS its B layout for the k-slice r, so no value ever moves between lanes;
+//   C. the X tiles go back over the M tiles.
+// Round 1 ran a 64-step substitution with two LDS reads per multiply-add (about 150 us per block and wave, the 16 ms of
+// k_pack64); this is 64 MFMAs plus 120 serial multiply-adds.
+__device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
+{
+    constexpr int R = PACK_LDM;   // row stride of Ms (padded: a stride of 64 doubles puts a whole column into one LDS bank)
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int li = lane & 15, lk = lane >> 4;
+    // ---- A: diagonal tiles
+    {
+        const int tile = lk, j = li;
+        const double *D = Ms + (16 * tile) * R + 16 * tile;
+        double xc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            double acc = (q == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < q; ++c) acc = fma(-D[q * R + c], xc[c], acc);
+            xc[q] = acc;
+        }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int q = 1; q < 16; ++q)
+            if (q > j) Ms[(16 * tile + q) * R + 16 * tile + j] = xc[q];
+        WAVE_LDS_FENCE();
+    }
+    // operand loaders.  A-layout: lane holds A[i = l&15][k = 4q + (l>>4)]; B-layout: B[k = 4q + (l>>4)][j = l&15]
+    auto loadA_full = [&](int ti, int tk, double(&a)[4]) {     // off-diagonal tile (ti > tk) of M
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = Ms[(16 * ti + li) * R + 16 * tk + 4 * q + lk];
+    };
+    auto loadA_diag = [&](int t, double(&a)[4]) {              // E_t: unit lower, stored strictly lower
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + lk;
+            const double v = Ms[(16 * t + li) * R + 16 * t + (k < li ? k : 0)];
+            a[q] = k < li ? v : (k == li ? 1.0 : 0.0);
+        }
+    };
+    auto loadB_diag = [&](int t, v4 &b) {                      // E_t in B-layout
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + lk;                          // row of E_t, column li
+            const double v = Ms[(16 * t + (k > li ? k : 15)) * R + 16 * t + (k > li ? li : 0)];
+            b[q] = k > li ? v : (k == li ? 1.0 : 0.0);
+        }
+    };
+    auto gemm = [&](const double(&a)[4], const v4 &b, v4 acc) -> v4 {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+        return acc;
+    };
+    // ---- B: X[i][j] for i > j, by increasing distance i - j
+    v4 X[4][4];
+#pragma unroll
+    for (int d = 1; d < 4; ++d) {
+#pragma unroll
+        for (int i = d; i < 4; ++i) {
+            const int j = i - d;
+            v4 S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = j; k < i; ++k) {
+                double a[4];
+                loadA_full(i, k, a);
+                v4 b;
+                if (k == j) loadB_diag(j, b);
+                else b = X[k][j];
+                S = gemm(a, b, S);
+            }
+            double e[4];
+            loadA_diag(i, e);
+            const v4 zero = {0.0, 0.0, 0.0, 0.0};
+            const v4 T = gemm(e, S, zero);
+            X[i][j] = -T;
+        }
+    }
+    WAVE_LDS_FENCE();   // every read of the M tiles precedes their replacement
+    // ---- C
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ms[(16 * i + lk + 4 * r) * R + 16 * j + li] = X[i][j][r];
+    WAVE_LDS_FENCE();
+}
+
 template <bool UPPER>
 __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const LuView &lv, int K,
                                             const ChainDesc &cd, int sb, double *T, double *dinv)
@@ -1207,34 +1303,37 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
         dinv[i0 + r] = di;
     }
     // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER).
-    // Loaded one DIAGONAL at a time: the 64 lanes then read 64 consecutive rows of one band diagonal (coalesced);
-    // lane-by-column order would gather 64 different diagonals per instruction.
-    for (int t = lane; t < R * R; t += 64) Ms[t] = 0.0;
-    WAVE_LDS_FENCE();
-    for (int d = 1; d <= Kn; ++d) {
-        if (d <= lane && rowok) {
-            if (!UPPER) Ms[lane * R + lane - d] = lu_get(lv, cd.row0, rl, rl - d);
-            else if (r + d < rows_here) Ms[lane * R + lane - d] = lu_get(lv, cd.row0, rl, rl + d) * di;
-        }
-    }
-    WAVE_LDS_FENCE();
-    // X = M^{-1}, lane = column j of X: X[q][j] = delta_qj - sum_{c<q} M[q][c] X[c][j]; row q of X replaces row q of M
-    for (int q = 0; q < R; ++q) {
-        double acc0 = (q == lane) ? 1.0 : 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        const double *mq = Ms + q * R;
-        // chunks of 8 columns with all 16 LDS reads issued before the FMAs.  Columns c >= q of row q are zero (M is
-        // strictly lower), so running a chunk past q multiplies not-yet-inverted rows by zero.
-        for (int c = 0; c < q; c += 8) {
-            double m[8], x[8];
+    // The lane's row of the 64 x 64 diagonal block is 4 x 128 contiguous bytes of the block-band scratch: all 32 16-byte
+    // loads are issued unconditionally and back to back (one memory latency), the triangle is selected afterwards.
+    // (Round 1 and the first block-band version loaded it one diagonal at a time under a per-lane condition: 63 dependent
+    //  round trips per side -- that, not the inversion, was most of the kernel's 15 ms.)
+    {
+        const int rbase = sb * R;                                  // chain-local row/column of the block's first entry
+        const int rb = rl >> 4;                                    // the lane's 16-row block (chain-local)
+        const double *rowp = lv.p + (((cd.row0 >> 4) + rb) * (int64_t)lv.ntl) * 256 + (rl & 15) * 16;
+        d2 rv[32];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { m[e] = mq[c + e]; x[e] = Ms[(c + e) * R + lane]; }
-            acc0 = fma(-m[0], x[0], acc0); acc1 = fma(-m[1], x[1], acc1); acc2 = fma(-m[2], x[2], acc2); acc3 = fma(-m[3], x[3], acc3);
-            acc0 = fma(-m[4], x[4], acc0); acc1 = fma(-m[5], x[5], acc1); acc2 = fma(-m[6], x[6], acc2); acc3 = fma(-m[7], x[7], acc3);
+        for (int q = 0; q < 32; ++q) {
+            const int c = rbase + 2 * q;                           // chain-local column of the pair
+            const int slot = (c >> 4) - rb + lv.KB;                // within [KB-3, KB+3]: always inside the scratch
+            rv[q] = *reinterpret_cast<const d2 *>(rowp + (int64_t)slot * 256 + (c & 15));
         }
-        WAVE_LDS_FENCE();  // every lane has read row q of M
-        Ms[q * R + lane] = (acc0 + acc1) + (acc2 + acc3);
-        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int cc = 2 * q + e;                          // block column of this entry
+                const double v = e == 0 ? rv[q].x : rv[q].y;
+                if (!UPPER) Ms[lane * PACK_LDM + cc] = (rowok && cc < lane) ? v : 0.0;
+                else {                                             // flipped: slot (lane, 63 - cc) <- U[r][cc] * di, cc > r
+                    const bool use = rowok && cc > r && cc < rows_here;
+                    Ms[lane * PACK_LDM + (R - 1 - cc)] = use ? v * di : 0.0;
+                }
+            }
+        }
     }
+    WAVE_LDS_FENCE();
+    invert_unit_lower_64(Ms, lane);   // the strictly lower triangle of Ms now holds that of M^{-1}
     // tile rows: lane = tile lane; entry d: in-block (d <= lane) = -X[lane][lane-d], else the band entry d rows/columns away
     // Every load is unconditional (clamped address, result selected afterwards) and the 16 entries of a wave slice are
     // unrolled, so the loads of a slice are in flight together.  (Measured: neither this nor the batched substitution
@@ -1248,7 +1347,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
                             (UPPER ? ((int64_t)sb * R + r + d < cd.nrows) : ((int64_t)sb * R + r - d >= 0));
         const int dd = far_ok ? d : 0;
         const double g = lu_get(lv, cd.row0, rl, UPPER ? rl + dd : rl - dd);
-        const double l = Ms[lane * R + (near ? lane - d : 0)];
+        const double l = Ms[lane * PACK_LDM + (near ? lane - d : 0)];
         return near ? -l : (far_ok ? (UPPER ? g * di : g) : 0.0);
     };
     for (int w = 0; w < NW; ++w) {
@@ -1267,7 +1366,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
 __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, LuView lv, int K, const ChainDesc *chains,
                                                const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
 {
-    __shared__ double Ms[64 * 64];
+    __shared__ double Ms[64 * PACK_LDM];
     const int sb = blockIdx.x, p = blockIdx.y;
     const ChainDesc cd = chains[p];
     if (sb >= cd.nsteps) return;

@@ -986,6 +986,361 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(LuView lv, const ChainD
     if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_factor_mfma_la: the same blocked LU with a LOOK-AHEAD schedule (round 2).  k_factor_mfma runs a block step as
+// [extract panel] | [16x16 LU, one wave] | [panel solves] | [write back] | [trailing update] with everybody waiting at every
+// bar: 21.6 us per step at K = 128 against 1.7 us of MFMA work (PMC: 67 % of the wave cycles parked at barriers/waits).
+// Here NW update waves own the window (as before) and one more wave owns the panel factorisation; a step is three phases:
+//   B(s)   panel wave: LU of the diagonal tile of step s      || update waves: the REST of the trailing update of step s-1
+//   C(s)   everybody: the panel solves of step s (division-free: the LU leaves the reciprocal pivots), then the write-back
+//   A(s+1) update waves: the update of step s restricted to the NEXT panel (block row / column s+1), which then moves from
+//          the accumulators to the other LDS panel buffer; the slots it frees are refilled with the entering tiles
+// so the serial chain per step is  next-panel update -> 16 pivots -> panel solves, and the bulk of the MFMA work (and all
+// global loads: the entering tiles, and the two panel tiles that were never in the window, fetched a step ahead) hides
+// behind the pivots.  Panels are double-buffered in LDS.
+// ------------------------------------------------------------------------------------------
+template <int KB, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, const ChainDesc *chains, double boost,
+                                                                  unsigned long long *nboost, unsigned long long *stamps)
+{
+    constexpr int RPW = KB / NW;
+    constexpr int NT = (NW + 1) * 64;
+    constexpr int PSZ = (2 * KB + 1) * TS;
+    constexpr int NTU = NW * 64;              // threads of the update waves
+    constexpr int NX = (512 + NTU - 1) / NTU; // elements of the two prefetched panel tiles per update thread
+    extern __shared__ double lds[];
+    double *rdiag = lds + 2 * PSZ;            // [2][16] reciprocal pivots of the panel in flight
+    const ChainDesc cd = chains[blockIdx.x];
+    const int64_t rs = cd.row0;
+    const int np = cd.nrows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool upd = w < NW;                  // wave NW factors the panels
+    const int nblk = (np + 15) / 16;
+    unsigned long long nb = 0;
+    // diagnostic build of the schedule (stamps != nullptr, SPIKE_FACTOR_STAMPS=1): shader-clock stamps of workgroup 0 at the
+    // phase boundaries of steps 64..71, slot = (step - 64) * 16 + wave_kind * 8 + point; never set in normal runs
+    auto stamp = [&](int s, int point) {
+        if (stamps != nullptr && blockIdx.x == 0 && lane == 0 && (w == 0 || w == NW) && s >= 64 && s < 72)
+            stamps[(s - 64) * 16 + (w == NW ? 8 : 0) + point] = __builtin_amdgcn_s_memtime();
+    };
+
+    auto ldA = [&](int rb, int cb, int row, int col) -> double {
+        const int r = 16 * rb + row, c = 16 * cb + col;  // partition-local
+        if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;  // identity padding past the partition end
+        return lu_get(lv, rs, r, c);
+    };
+    // a tile that lies inside the chain and inside the scratch is 2 KiB contiguous, and (row = (lane>>4) + 4q, col = lane&15)
+    // is element lane + 64 q of it: four fully coalesced 512-byte loads, one scalar base address per tile
+    const int64_t rbg0 = rs >> 4;
+    auto tile_inside = [&](int rb, int cb) -> bool {
+        return 16 * (rb + 1) <= np && 16 * (cb + 1) <= np && cb - rb + lv.KB >= 0 && cb - rb + lv.KB < lv.ntl;
+    };
+    auto tile_base = [&](int rb, int cb) -> double * { return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256; };
+    auto load_tile = [&](v4d &t, int rb, int cb) {
+        if (tile_inside(rb, cb)) {
+            const double *tp = tile_base(rb, cb) + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
+        }
+    };
+    auto store_tile = [&](const v4d &t, double *dst) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
+    };
+
+    v4d acc[RPW][KB];
+    if (upd) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int b = 0; b < KB; ++b) load_tile(acc[rr][b], rr * NW + w, b);
+    }
+
+    // the two panel tiles of step sx that never enter the window, (sx+KB, sx) and (sx, sx+KB): raw band entries, fetched
+    // into registers one step ahead and put into the panel buffer when that panel is extracted
+    double xt[NX];
+    auto fetch_extra = [&](int sx) {
+        const bool in0 = tile_inside(sx + KB, sx), in1 = tile_inside(sx, sx + KB);
+        const double *b0 = in0 ? tile_base(sx + KB, sx) : lv.p, *b1 = in1 ? tile_base(sx, sx + KB) : lv.p;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int e = tid + q * NTU;      // update threads only: the panel wave is busy with the LU when this runs
+            const int row = (e >> 4) & 15, col = e & 15;
+            if (e >= 512 || !upd) xt[q] = 0.0;
+            else if ((e >> 8) == 0) xt[q] = in0 ? b0[e & 255] : ldA(sx + KB, sx, row, col);
+            else xt[q] = in1 ? b1[e & 255] : ldA(sx, sx + KB, row, col);
+        }
+    };
+    // panel of step s: registers -> LDS buffer P; the freed slots take the entering tiles
+    auto extract = [&](int s, double *P, int mode) {   // mode 0: everything, 1: the diagonal tile only, 2: all but it
+        double *Pd = P, *Pc = P + TS, *Pr = P + TS + KB * TS;
+        const int as = s % KB;
+        // Entering tiles: block row s+KB (tiles (s+KB, s+1 .. s+KB): slots 1 .. KB of that row block, 16 KiB contiguous) and
+        // block column s+KB (tile (s+I, s+KB): slot 2KB - I of row block s+I).  They all lie inside the chain iff block
+        // s+KB does -- ONE uniform test for the whole step instead of bounds logic per tile (the wave that owns the pivot
+        // row moves eight tiles here: it was the slowest wave of every step).
+        const bool fast = 16 * (s + KB + 1) <= np;
+        const double *rowbase = lv.p + ((rbg0 + s + KB) * lv.ntl) * 256 + lane;
+        if (upd) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int a = rr * NW + w;
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const bool isdiag = a == as && b == as;
+                    if ((mode == 1 && !isdiag) || (mode == 2 && isdiag)) continue;
+                    if (a == as) {
+                        const int J = (b - as + KB) % KB;  // tile (s, s+J)
+                        store_tile(acc[rr][b], J == 0 ? Pd : Pr + (J - 1) * TS);
+                        const int Jn = (b - as - 1 + KB) % KB + 1;  // new tile (s+KB, s+Jn)
+                        if (fast) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[rr][b][q] = rowbase[Jn * 256 + 64 * q];
+                        } else load_tile(acc[rr][b], s + KB, s + Jn);
+                    } else if (b == as) {
+                        const int I = (a - as + KB) % KB;  // tile (s+I, s), I in 1..KB-1
+                        store_tile(acc[rr][b], Pc + (I - 1) * TS);
+                        if (fast) {                            // new tile (s+I, s+KB)
+                            const double *cb = lv.p + ((rbg0 + s + I) * lv.ntl + (2 * KB - I)) * 256 + lane;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[rr][b][q] = cb[64 * q];
+                        } else load_tile(acc[rr][b], s + I, s + KB);
+                    }
+                }
+            }
+        }
+        if (mode != 1 && upd) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                const int e = tid + q * NTU;
+                if (e < 512) {
+                    const int row = (e >> 4) & 15, col = e & 15;
+                    ((e >> 8) == 0 ? Pc : Pr)[(KB - 1) * TS + row * LDT + col] = xt[q];
+                }
+            }
+        }
+    };
+    // trailing update of step s from panel buffer P: tile(s+I, s+J) -= L21[I] * U12[J]; diag_only: just the next diagonal
+    // tile (I == J == 1), else everything but it
+    auto update = [&](int s, const double *P, bool diag_only) {
+        const double *Pc = P + TS, *Pr = P + TS + KB * TS;
+        const int as = s % KB;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int a = rr * NW + w;
+            const int I = (a - as - 1 + KB) % KB + 1;
+            if (diag_only && I != 1) continue;
+            const double *Lp = Pc + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
+            double la[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) la[q] = -Lp[4 * q];
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int J = (b - as - 1 + KB) % KB + 1;
+                if ((I == 1 && J == 1) != diag_only) continue;
+                const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[rr][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Up[4 * q * LDT], acc[rr][b], 0, 0, 0);
+            }
+        }
+    };
+    // 16 x 16 LU of the diagonal tile in panel buffer P (panel wave only); leaves the reciprocal pivots in rd.
+    // The 16 pivots are ONE dependent chain (16384 of them per chain run through here one after another), and this wave
+    // shares the LDS with eight busy update waves, so the chain must not go through LDS: lane j (< 16) holds COLUMN j of
+    // the tile in 16 registers; per pivot k the pivot and the multipliers live in lane k and reach the other lanes by
+    // v_readlane (scalar registers, no memory pipe), every lane then updates its own column with scalar-operand FMAs.
+    // Two LDS round trips per tile (load, store) instead of one per pivot (first round-2 version: 700 cycles per pivot
+    // alone, 1400 beside the update waves) or four to five plus an IEEE divide (round 1: 1100).  The reciprocal pivot is
+    // v_rcp_f64 + two Newton steps.
+    auto panel_lu = [&](int s, double *Pd, double *rd) {
+        const int j = lane & 15;
+        double e[16], rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = Pd[r * LDT + j];
+        // this wave is the youngest of its SIMD and would lose every issue arbitration against the MFMA streams of the
+        // update waves beside it (priority, then age); its chain is what the whole workgroup waits for
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e[k]), k),
+                                          __builtin_amdgcn_readlane(__double2loint(e[k]), k));
+            const bool real_row = 16 * s + k < np;
+            if (real_row && fabs(piv) < boost) {
+                piv = (piv < 0.0) ? -boost : boost;
+                if (lane == 0) ++nb;
+                if (j == k) e[k] = piv;                                // the pivot's owner keeps the boosted pivot
+            }
+            double rinv = __builtin_amdgcn_rcp(piv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+            rv[k] = rinv;
+            const double uk = e[k];                                    // U[k][j] (final for j >= k)
+#pragma unroll
+            for (int r = k + 1; r < 16; ++r) {
+                // multiplier l[r] = A[r][k] / pivot: computed in lane k, read by everybody
+                const double lk = e[r] * rinv;
+                const double l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lk), k),
+                                                  __builtin_amdgcn_readlane(__double2loint(lk), k));
+                if (j > k) e[r] = fma(-l, uk, e[r]);
+                else if (j == k) e[r] = l;                             // the multiplier replaces the eliminated entry
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (lane < 16) Pd[r * LDT + j] = e[r];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rd[k] = rv[k];
+        }
+    };
+
+    // Schedule (three barriers per step):
+    //   P1(s)  everybody: the panel solves of step s (division-free: the LU left the reciprocal pivots)
+    //   P2(s)  the owner of the NEXT diagonal tile updates it (4 MFMAs) and moves it to the other panel buffer
+    //   P3(s)  panel wave: LU of that tile  ||  update waves: the rest of the trailing update of step s, the rest of
+    //          panel s+1 to the other buffer (freed slots refilled with the entering tiles), the write-back of step s
+    // so the 16 serial pivots of step s+1 hide behind everything else of step s.
+    fetch_extra(0);
+    extract(0, lds, 0);
+    fetch_extra(1);
+    __syncthreads();
+    if (!upd) panel_lu(0, lds, rdiag);
+    __syncthreads();
+    for (int s = 0; s < nblk; ++s) {
+        double *cur = lds + (s & 1) * PSZ, *nxt = lds + ((s + 1) & 1) * PSZ;
+        double *Pd = cur, *Pc = cur + TS, *Pr = cur + TS + KB * TS;
+        const double *rd = rdiag + (s & 1) * 16;
+        const bool more = s + 1 < nblk;
+        // ---- P1(s): L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
+        stamp(s, 0);
+        for (int t = tid; t < 2 * 16 * KB; t += NT) {
+            const int which = t / (16 * KB), idx = t % (16 * KB), tile = idx >> 4, line = idx & 15;
+            double x[16];
+            if (which == 0) {
+                double *T = Pc + tile * TS + line * LDT;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = T[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= x[k] * Pd[k * LDT + c];
+                    x[c] = v * rd[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[c] = x[c];
+            } else {
+                double *T = Pr + tile * TS + line;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) x[rr] = T[rr * LDT];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    double v = x[rr];
+#pragma unroll
+                    for (int k = 0; k < rr; ++k) v -= Pd[rr * LDT + k] * x[k];
+                    x[rr] = v;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) T[rr * LDT] = x[rr];
+            }
+        }
+        stamp(s, 1);
+        __syncthreads();
+        stamp(s, 2);
+        // ---- P2(s)
+        if (more && upd) {
+            update(s, cur, true);
+            extract(s + 1, nxt, 1);
+        }
+        stamp(s, 3);
+        __syncthreads();
+        stamp(s, 4);
+        // ---- P3(s)
+        if (!upd) {
+            if (more) panel_lu(s + 1, nxt, rdiag + ((s + 1) & 1) * 16);
+            stamp(s, 5);
+        } else {
+            if (more) {
+                update(s, cur, false);
+                extract(s + 1, nxt, 2);
+                fetch_extra(s + 2);
+            }
+            stamp(s, 5);
+            // write the finished block row / block column back: a tile inside the chain is 2 KiB contiguous in the
+            // scratch; the 2 KB+1 tiles are dealt to the update waves, a tile = 4 LDS reads + 4 coalesced 512-byte stores
+            for (int tile = w; tile <= 2 * KB; tile += NW) {
+                int rb, cb;
+                const double *T;
+                if (tile == 0) { rb = s; cb = s; T = Pd; }
+                else if (tile <= KB) { rb = s + tile; cb = s; T = Pc + (tile - 1) * TS; }
+                else { rb = s; cb = s + tile - KB; T = Pr + (tile - KB - 1) * TS; }
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = T[((lane >> 4) + 4 * q) * LDT + (lane & 15)];
+                if (tile_inside(rb, cb)) {
+                    double *tp = tile_base(rb, cb) + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tp[64 * q] = v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr2 = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
+                        if (rr2 < np && c < np) lu_put(lv, rs, rr2, c, v[q]);
+                    }
+                }
+            }
+        }
+        stamp(s, 6);
+        __syncthreads();
+        stamp(s, 7);
+    }
+    if (lane == 0 && !upd && nb) atomicAdd(nboost, nb);
+}
+
+template <int KB, int NW>
+static hipError_t launch_factor_mfma_la_t(const LuView &lv, const ChainDesc *chains, int nchains, double boost,
+                                          unsigned long long *nboost, hipStream_t st)
+{
+    const size_t shm = ((size_t)2 * (2 * KB + 1) * TS + 32) * sizeof(double);
+    if (shm > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma_la<KB, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+    }
+    unsigned long long *stamps = nullptr;
+    if (getenv("SPIKE_FACTOR_STAMPS")) {   // diagnostic: print the phase times of steps 64..71 of workgroup 0
+        if (hipMalloc((void **)&stamps, 128 * sizeof(unsigned long long)) != hipSuccess) stamps = nullptr;
+        else (void)hipMemsetAsync(stamps, 0, 128 * sizeof(unsigned long long), st);
+    }
+    hipLaunchKernelGGL((k_factor_mfma_la<KB, NW>), dim3(nchains), dim3((NW + 1) * 64), shm, st, lv, chains, boost, nboost, stamps);
+    hipError_t e = hipGetLastError();
+    if (stamps) {
+        unsigned long long hs[128];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hs, stamps, sizeof hs, hipMemcpyDeviceToHost);
+        (void)hipFree(stamps);
+        const char *names[7] = {"P1: panel solves", "barrier", "P2: next diag tile", "barrier", "P3: LU | upd+extract", "P3: write-back", "barrier"};
+        for (int kind = 0; kind < 2; ++kind) {
+            fprintf(stderr, "[factor stamps] %s wave, shader cycles per phase, steps 64..71:\n", kind ? "panel" : "update");
+            for (int ph = 0; ph < 7; ++ph) {
+                fprintf(stderr, "  %-22s", names[ph]);
+                for (int sidx = 0; sidx < 8; ++sidx) fprintf(stderr, " %6lld", (long long)(hs[sidx * 16 + kind * 8 + ph + 1] - hs[sidx * 16 + kind * 8 + ph]));
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "  %-22s", "whole step");
+            for (int sidx = 0; sidx < 7; ++sidx) fprintf(stderr, " %6lld", (long long)(hs[(sidx + 1) * 16 + kind * 8] - hs[sidx * 16 + kind * 8]));
+            fprintf(stderr, "\n");
+        }
+    }
+    return e;
+}
+
 // Same algorithm with the trailing window left in global memory (L2 / Infinity Cache resident) and updated in place:
 // used when the K x K window (512 KiB at K = 256) does not fit the register file of one CU.
 template <int KB, int NW>
@@ -1079,8 +1434,13 @@ hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains,
     if (K <= 16) return launch_factor_mfma_t<1, 1>(lv, chains, nchains, boost, nboost, st);
     if (K <= 32) return launch_factor_mfma_t<2, 2>(lv, chains, nchains, boost, nboost, st);
     lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;   // block-band scratch: as wide as the kernels' window
-    if (K <= 64) return launch_factor_mfma_t<4, 4>(lv, chains, nchains, boost, nboost, st);
-    if (K <= 128) return launch_factor_mfma_t<8, 4>(lv, chains, nchains, boost, nboost, st);
+    static const bool old_schedule = getenv("SPIKE_FACTOR_OLD") != nullptr;   // measurement knob: the round-1 schedule
+    if (old_schedule) {
+        if (K <= 64) return launch_factor_mfma_t<4, 4>(lv, chains, nchains, boost, nboost, st);
+        if (K <= 128) return launch_factor_mfma_t<8, 4>(lv, chains, nchains, boost, nboost, st);
+    }
+    if (K <= 64) return launch_factor_mfma_la_t<4, 4>(lv, chains, nchains, boost, nboost, st);
+    if (K <= 128) return launch_factor_mfma_la_t<8, 8>(lv, chains, nchains, boost, nboost, st);
     return launch_factor_mfma_inplace_t<16, 8>(lv, chains, nchains, boost, nboost, st);
 }
 

@@ -986,6 +986,89 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(LuView lv, const ChainD
     if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
 }
 
+// 16 x 16 LU of a diagonal tile held in LDS (one wave), see the comment at its call site in k_factor_mfma_la
+__device__ __forceinline__ void tile_lu_regs(int s, double *Pd, double *rd, int np, double boost, unsigned long long &nb, int lane)
+{
+    const int j = lane & 15;
+    double e[16], rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = Pd[r * LDT + j];
+    // this wave is the youngest of its SIMD and would lose every issue arbitration against the MFMA streams of the
+    // update waves beside it (priority, then age); its chain is what the whole workgroup waits for
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e[k]), k),
+                                      __builtin_amdgcn_readlane(__double2loint(e[k]), k));
+        const bool real_row = 16 * s + k < np;
+        if (real_row && fabs(piv) < boost) {
+            piv = (piv < 0.0) ? -boost : boost;
+            if (lane == 0) ++nb;
+            if (j == k) e[k] = piv;                                // the pivot's owner keeps the boosted pivot
+        }
+        double rinv = __builtin_amdgcn_rcp(piv);
+        rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+        rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+        rv[k] = rinv;
+        const double uk = e[k];                                    // U[k][j] (final for j >= k)
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r) {
+            // multiplier l[r] = A[r][k] / pivot: computed in lane k, read by everybody
+            const double lk = e[r] * rinv;
+            const double l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lk), k),
+                                              __builtin_amdgcn_readlane(__double2loint(lk), k));
+            if (j > k) e[r] = fma(-l, uk, e[r]);
+            else if (j == k) e[r] = l;                             // the multiplier replaces the eliminated entry
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (lane < 16) Pd[r * LDT + j] = e[r];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) rd[k] = rv[k];
+    }
+}
+
+// panel solves of one block step, division-free (rd = reciprocal pivots left by tile_lu_regs):
+// L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
+template <int KB, int NT>
+__device__ __forceinline__ void panel_solves(const double *Pd, double *Pc, double *Pr, const double *rd, int tid)
+{
+    for (int t = tid; t < 2 * 16 * KB; t += NT) {
+        const int which = t / (16 * KB), idx = t % (16 * KB), tile = idx >> 4, line = idx & 15;
+        double x[16];
+        if (which == 0) {
+            double *T = Pc + tile * TS + line * LDT;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = T[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) v -= x[k] * Pd[k * LDT + c];
+                x[c] = v * rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) T[c] = x[c];
+        } else {
+            double *T = Pr + tile * TS + line;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) x[rr] = T[rr * LDT];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                double v = x[rr];
+#pragma unroll
+                for (int k = 0; k < rr; ++k) v -= Pd[rr * LDT + k] * x[k];
+                x[rr] = v;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) T[rr * LDT] = x[rr];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_factor_mfma_la: the same blocked LU with a LOOK-AHEAD schedule (round 2).  k_factor_mfma runs a block step as
 // [extract panel] | [16x16 LU, one wave] | [panel solves] | [write back] | [trailing update] with everybody waiting at every
@@ -1157,48 +1240,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     // Two LDS round trips per tile (load, store) instead of one per pivot (first round-2 version: 700 cycles per pivot
     // alone, 1400 beside the update waves) or four to five plus an IEEE divide (round 1: 1100).  The reciprocal pivot is
     // v_rcp_f64 + two Newton steps.
-    auto panel_lu = [&](int s, double *Pd, double *rd) {
-        const int j = lane & 15;
-        double e[16], rv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = Pd[r * LDT + j];
-        // this wave is the youngest of its SIMD and would lose every issue arbitration against the MFMA streams of the
-        // update waves beside it (priority, then age); its chain is what the whole workgroup waits for
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e[k]), k),
-                                          __builtin_amdgcn_readlane(__double2loint(e[k]), k));
-            const bool real_row = 16 * s + k < np;
-            if (real_row && fabs(piv) < boost) {
-                piv = (piv < 0.0) ? -boost : boost;
-                if (lane == 0) ++nb;
-                if (j == k) e[k] = piv;                                // the pivot's owner keeps the boosted pivot
-            }
-            double rinv = __builtin_amdgcn_rcp(piv);
-            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
-            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
-            rv[k] = rinv;
-            const double uk = e[k];                                    // U[k][j] (final for j >= k)
-#pragma unroll
-            for (int r = k + 1; r < 16; ++r) {
-                // multiplier l[r] = A[r][k] / pivot: computed in lane k, read by everybody
-                const double lk = e[r] * rinv;
-                const double l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lk), k),
-                                                  __builtin_amdgcn_readlane(__double2loint(lk), k));
-                if (j > k) e[r] = fma(-l, uk, e[r]);
-                else if (j == k) e[r] = l;                             // the multiplier replaces the eliminated entry
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (lane < 16) Pd[r * LDT + j] = e[r];
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) rd[k] = rv[k];
-        }
-    };
+    auto panel_lu = [&](int s, double *Pd, double *rd) { tile_lu_regs(s, Pd, rd, np, boost, nb, lane); };
 
     // Schedule (three barriers per step):
     //   P1(s)  everybody: the panel solves of step s (division-free: the LU left the reciprocal pivots)
@@ -1219,37 +1261,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
         const bool more = s + 1 < nblk;
         // ---- P1(s): L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
         stamp(s, 0);
-        for (int t = tid; t < 2 * 16 * KB; t += NT) {
-            const int which = t / (16 * KB), idx = t % (16 * KB), tile = idx >> 4, line = idx & 15;
-            double x[16];
-            if (which == 0) {
-                double *T = Pc + tile * TS + line * LDT;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = T[c];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    double v = x[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) v -= x[k] * Pd[k * LDT + c];
-                    x[c] = v * rd[c];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) T[c] = x[c];
-            } else {
-                double *T = Pr + tile * TS + line;
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) x[rr] = T[rr * LDT];
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    double v = x[rr];
-#pragma unroll
-                    for (int k = 0; k < rr; ++k) v -= Pd[rr * LDT + k] * x[k];
-                    x[rr] = v;
-                }
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) T[rr * LDT] = x[rr];
-            }
-        }
+        panel_solves<KB, NT>(Pd, Pc, Pr, rd, tid);
         stamp(s, 1);
         __syncthreads();
         stamp(s, 2);
@@ -1350,6 +1362,7 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(LuView lv, cons
     constexpr int NT = NW * 64;
     extern __shared__ double lds[];
     double *Pd = lds, *Pc = lds + TS, *Pr = lds + TS + KB * TS;
+    double *rd = lds + (2 * KB + 1) * TS;   // 16 reciprocal pivots
     const ChainDesc cd = chains[blockIdx.x];
     const int64_t rs = cd.row0;
     const int np = cd.nrows;
@@ -1362,30 +1375,99 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(LuView lv, cons
         if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;
         return lu_get(lv, rs, r, c);
     };
+    // round 2: a tile inside the chain is 2 KiB contiguous in the block-band scratch and (row = (lane>>4)+4q, col = lane&15)
+    // is its element lane + 64 q: whole-tile moves are four coalesced 512-byte accesses with one scalar base address
+    const int64_t rbg0 = rs >> 4;
+    auto tile_inside = [&](int rb, int cb) -> bool {
+        return 16 * (rb + 1) <= np && 16 * (cb + 1) <= np && cb - rb + lv.KB >= 0 && cb - rb + lv.KB < lv.ntl;
+    };
+    auto tile_base = [&](int rb, int cb) -> double * { return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256; };
+    auto load_tile = [&](double(&t)[4], int rb, int cb) {
+        if (tile_inside(rb, cb)) {
+            const double *tp = tile_base(rb, cb) + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
+        }
+    };
+    auto store_tile_g = [&](const double(&t)[4], int rb, int cb) {
+        if (tile_inside(rb, cb)) {
+            double *tp = tile_base(rb, cb) + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tp[64 * q] = t[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
+                if (r < np && c < np) lu_put(lv, rs, r, c, t[q]);
+            }
+        }
+    };
+    auto panel_tile = [&](int tile, int s, int &rb, int &cb) -> double * {
+        if (tile == 0) { rb = s; cb = s; return Pd; }
+        if (tile <= KB) { rb = s + tile; cb = s; return Pc + (tile - 1) * TS; }
+        rb = s; cb = s + tile - KB; return Pr + (tile - KB - 1) * TS;
+    };
     for (int s = 0; s < nblk; ++s) {
-        for (int t = tid; t < (2 * KB + 1) * 256; t += NT) {
-            const int tile = t >> 8, row = (t >> 4) & 15, col = t & 15;
-            if (tile == 0) Pd[row * LDT + col] = ldA(s, s, row, col);
-            else if (tile <= KB) Pc[(tile - 1) * TS + row * LDT + col] = ldA(s + tile, s, row, col);
-            else Pr[(tile - KB - 1) * TS + row * LDT + col] = ldA(s, s + tile - KB, row, col);
+        // panel of step s: scratch -> LDS, a tile per wave at a time
+        for (int tile = w; tile <= 2 * KB; tile += NW) {
+            int rb, cb;
+            double *T = panel_tile(tile, s, rb, cb);
+            double t[4];
+            load_tile(t, rb, cb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
         }
         __syncthreads();
-        panel_phase<KB, NT>(Pd, Pc, Pr, s, np, rs, lv, boost, nb, tid, lane, w);
-        for (int t = w; t < KB * KB; t += NW) {
-            const int I = t / KB + 1, J = t % KB + 1;
-            if (16 * (s + I) >= np || 16 * (s + J) >= np) continue;
-            v4d acc;
+        if (w == 0) tile_lu_regs(s, Pd, rd, np, boost, nb, lane);
+        __syncthreads();
+        panel_solves<KB, NT>(Pd, Pc, Pr, rd, tid);
+        __syncthreads();
+        // the finished block row / column goes back (whole tiles), then the trailing update of the K x K window in place
+        // in L2: two tiles per wave in flight (8 loads) before their 8 MFMAs and 8 stores
+        for (int tile = w; tile <= 2 * KB; tile += NW) {
+            int rb, cb;
+            const double *T = panel_tile(tile, s, rb, cb);
+            double t[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = ldA(s + I, s + J, (lane >> 4) + 4 * q, lane & 15);
+            for (int q = 0; q < 4; ++q) t[q] = T[((lane >> 4) + 4 * q) * LDT + (lane & 15)];
+            store_tile_g(t, rb, cb);
+        }
+        // Software-pipelined: the loads of the NEXT pair of tiles are issued before the MFMAs and stores of the current
+        // pair.  Vector-memory operations complete in order, so a wave that issues load - MFMA - store - load ... waits for
+        // its own previous stores (a full L2 write round trip) before every load; with the loads ahead of the stores the
+        // wait for them (vmcnt(8)) leaves the stores in flight.
+        auto tile_on = [&](int t) -> bool {
+            const int I = t / KB + 1, J = t % KB + 1;
+            return t < KB * KB && 16 * (s + I) < np && 16 * (s + J) < np;
+        };
+        auto tile_load = [&](int t, double(&a)[4]) { if (tile_on(t)) load_tile(a, s + t / KB + 1, s + t % KB + 1); };
+        auto tile_update_store = [&](int t, double(&a)[4]) {
+            if (!tile_on(t)) return;
+            const int I = t / KB + 1, J = t % KB + 1;
+            v4d acc = {a[0], a[1], a[2], a[3]};
             const double *Lp = Pc + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
             const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[4 * q], Up[4 * q * LDT], acc, 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 16 * (s + I) + (lane >> 4) + 4 * q, c = 16 * (s + J) + (lane & 15);
-                if (r < np && c < np) lu_put(lv, rs, r, c, acc[q]);
-            }
+            for (int q = 0; q < 4; ++q) a[q] = acc[q];
+            store_tile_g(a, s + I, s + J);
+        };
+        double pa0[4], pa1[4], pb0[4], pb1[4];
+        tile_load(w, pa0);
+        tile_load(w + NW, pa1);
+        for (int t0 = w; t0 < KB * KB; t0 += 4 * NW) {
+            tile_load(t0 + 2 * NW, pb0);
+            tile_load(t0 + 3 * NW, pb1);
+            tile_update_store(t0, pa0);
+            tile_update_store(t0 + NW, pa1);
+            tile_load(t0 + 4 * NW, pa0);
+            tile_load(t0 + 5 * NW, pa1);
+            tile_update_store(t0 + 2 * NW, pb0);
+            tile_update_store(t0 + 3 * NW, pb1);
         }
         __syncthreads();
     }
@@ -1396,7 +1478,7 @@ template <int KB, int NW>
 static hipError_t launch_factor_mfma_inplace_t(const LuView &lv, const ChainDesc *chains, int nchains,
                                                double boost, unsigned long long *nboost, hipStream_t st)
 {
-    const size_t shm = (size_t)(2 * KB + 1) * TS * sizeof(double);
+    const size_t shm = ((size_t)(2 * KB + 1) * TS + 16) * sizeof(double);
     if (shm > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma_inplace<KB, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

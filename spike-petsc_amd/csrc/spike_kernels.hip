@@ -2178,13 +2178,17 @@ __global__ __launch_bounds__(256) void k_iface_setup(int K, const double *Wall, 
 // pivoting (row swaps recorded, undone as one column permutation when the inverse is written out).  One 1024-thread
 // workgroup per interface, lane = column: a block step touches LDS only -- the global-memory version above moves the
 // augmented K x 2K matrix through L2 once per pivot (8 ms for 255 interfaces at K = 128, against 0.3 ms here).
+// GLOBAL = true (K > 128: the matrix does not fit the CU's LDS): the same in-place algorithm with the K x (K+1) matrix in a
+// global work area (it stays in L2: 0.5 MB per interface at K = 256) and only the pivot row/column in LDS -- half the traffic
+// of the augmented [S | I] form of k_iface_setup and four times its threads per interface.
+template <bool GLOBAL>
 __global__ __launch_bounds__(1024) void k_iface_setup_lds(int K, const double *Wall, const double *Vall, double *WTall,
-                                                          double *VTall, double *STall, int *flag)
+                                                          double *VTall, double *STall, int *flag, double *workall)
 {
     extern __shared__ double sh[];
     const int LD = K + 1;
-    double *A = sh;                     // K x LD
-    double *rowk = A + (size_t)K * LD;  // K
+    double *A = GLOBAL ? workall + (size_t)blockIdx.x * K * LD : sh;   // K x LD
+    double *rowk = GLOBAL ? sh : sh + (size_t)K * LD;                  // K
     double *colk = rowk + K;            // K
     double *rmax = colk + K;            // 16 (one per wave)
     int *ridx = reinterpret_cast<int *>(rmax + 16);  // 16
@@ -2274,18 +2278,19 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
     if (K <= 128) {
         const int nt = K <= 8 ? 64 : (K <= 32 ? 256 : 1024);
         const size_t lds = ((size_t)K * (K + 1) + 2 * K + 16) * sizeof(double) + (16 + 2 * (size_t)K) * sizeof(int);
-        static size_t lds_allowed = 48 * 1024;   // beyond this the kernel needs its dynamic-LDS limit raised (once)
-        bool ok = lds <= lds_allowed;
-        if (!ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_iface_setup_lds),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
-            lds_allowed = lds;
-            ok = true;
-        }
+        // beyond 48 KiB the kernel needs its dynamic-LDS limit raised (cheap, so simply every time: no process-global state)
+        bool ok = lds <= 48 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void *>(k_iface_setup_lds<false>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         if (!ok) (void)hipGetLastError();   // this device cannot give one workgroup that much LDS: global-memory version
         if (ok) {
-            hipLaunchKernelGGL(k_iface_setup_lds, dim3(nif), dim3(nt), lds, st, K, W, V, WT, VT, ST, flag);
+            hipLaunchKernelGGL(k_iface_setup_lds<false>, dim3(nif), dim3(nt), lds, st, K, W, V, WT, VT, ST, flag, (double *)nullptr);
             return hipGetLastError();
         }
+    }
+    if (work != nullptr) {   // the caller's work area holds 2 K^2 doubles per interface >= K (K+1)
+        const size_t lds = ((size_t)2 * K + 16) * sizeof(double) + (16 + 2 * (size_t)K) * sizeof(int);
+        hipLaunchKernelGGL(k_iface_setup_lds<true>, dim3(nif), dim3(1024), lds, st, K, W, V, WT, VT, ST, flag, work);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(k_iface_setup, dim3(nif), dim3(256), (size_t)3 * K * sizeof(double), st, K, W, V, WT, VT, ST,
                        work, flag);

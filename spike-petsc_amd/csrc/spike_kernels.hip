@@ -448,9 +448,9 @@ static hipError_t launch_sweep_multi_t(bool rev, int nchains, const SweepArgs &a
 // right-hand sides per launch for this configuration (setup asks before it sizes its buffers).  The tile layout does not
 // depend on how the diagonals are dealt to waves, so the batched solves use 16 diagonals per wave: half the tile
 // registers per wave leave room for FOUR right-hand sides per pass over the factors (with 32 diagonals per wave a third
-// vector already pushed the kernel past 256 VGPRs: round 1).  K > 128 would need more than 8 such waves at 128 VGPRs
-// each and keeps two vectors.
-int sweep_multi_nr(const SweepCfg &cfg) { return (cfg.R == 64 && !cfg.scan && cfg.NW <= 4) ? 4 : 2; }
+// vector already pushed the kernel past 256 VGPRs: round 1).  K > 192 would need 16 such waves at 128 VGPRs each (measured:
+// spills, no gain) and keeps two vectors on 32-diagonal waves.
+int sweep_multi_nr(const SweepCfg &cfg) { return (cfg.R == 64 && !cfg.scan && cfg.NW <= 6) ? 4 : 2; }
 
 // one chain per workgroup (groups[p] describes chain p): configurations with R = 64 only
 hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const SweepArgs &a, int64_t ldr, hipStream_t st)
@@ -461,7 +461,7 @@ hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const 
     case 2: return launch_sweep_multi_t<16, 4, 4>(rev, nchains, a, ldr, st);
     case 3: return launch_sweep_multi_t<16, 6, 4>(rev, nchains, a, ldr, st);
     case 4: return launch_sweep_multi_t<16, 8, 4>(rev, nchains, a, ldr, st);
-    case 6: return launch_sweep_multi_t<32, 6, 2>(rev, nchains, a, ldr, st);
+    case 6: return launch_sweep_multi_t<16, 12, 4>(rev, nchains, a, ldr, st);
     case 8: return launch_sweep_multi_t<32, 8, 2>(rev, nchains, a, ldr, st);
     }
     return hipErrorInvalidValue;

@@ -208,12 +208,14 @@ int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *adj, const do
 int spike_fd_destroy(spike_fd_ctx *c);
 int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *ib, double *sums); /* nd <= 6 dot products */
 int spike_fd_lap(spike_fd_ctx *c, int src, int dst);                                    /* v[dst] = L v[src]   */
-int spike_fd_resid(spike_fd_ctx *c, double rho, double *rn2);                           /* w = Lx - rho x      */
-int spike_fd_precond(spike_fd_ctx *c, double *sum);                                     /* w /= deg            */
 int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
-int spike_fd_axpy(spike_fd_ctx *c, double a, int x, int y, int x2, int y2);
 int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
-int spike_fd_update(spike_fd_ctx *c, double c0, double c1, double c2, int havep);
+/* fused steps of the iteration (element-wise statements, then the step's sums over the updated values) */
+int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums); /* |w|^2, sum w  */
+int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums);                 /* w.x, p.x      */
+int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums);           /* p.p, w.p      */
+int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww);
+int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx);
 int spike_fd_fill_alternating(spike_fd_ctx *c);
 int spike_fd_download_x(spike_fd_ctx *c, double *x);
 

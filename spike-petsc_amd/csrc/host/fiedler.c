@@ -190,14 +190,15 @@ int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *adj, const do
 int spike_fd_destroy(spike_fd_ctx *c);
 int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *ib, double *sums);
 int spike_fd_lap(spike_fd_ctx *c, int src, int dst);
-int spike_fd_resid(spike_fd_ctx *c, double rho, double *rn2);
-int spike_fd_precond(spike_fd_ctx *c, double *sum);
 int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
-int spike_fd_axpy(spike_fd_ctx *c, double a, int x, int y, int x2, int y2);
 int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
-int spike_fd_update(spike_fd_ctx *c, double c0, double c1, double c2, int havep);
 int spike_fd_fill_alternating(spike_fd_ctx *c);
 int spike_fd_download_x(spike_fd_ctx *c, double *x);
+int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums);
+int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums);
+int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums);
+int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww);
+int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx);
 
 typedef struct {
     const graph_t *g;
@@ -218,30 +219,10 @@ static void op_lap(vecs_t *V, int src, int dst)
     if (V->dev) { if (spike_fd_lap(V->dev, src, dst)) V->err = 1; return; }
     lap_mult(V->g, V->v[src], V->v[dst]);
 }
-static double op_resid(vecs_t *V, double rho)   /* w = Lx - rho x; returns sum w_i^2 */
-{
-    double rn2 = 0.0;
-    if (V->dev) { if (spike_fd_resid(V->dev, rho, &rn2)) V->err = 1; return rn2; }
-    for (I i = 0; i < V->n; ++i) V->v[2][i] = V->v[1][i] - rho * V->v[0][i];
-    return dot(V->n, V->v[2], V->v[2]);
-}
-static double op_precond(vecs_t *V)   /* w_i /= deg_i (1 for isolated vertices); returns sum w_i */
-{
-    double s = 0.0;
-    if (V->dev) { if (spike_fd_precond(V->dev, &s)) V->err = 1; return s; }
-    for (I i = 0; i < V->n; ++i) V->v[2][i] /= (V->g->deg[i] > 0 ? V->g->deg[i] : 1.0);
-    return dot(V->n, V->v[2], NULL);
-}
 static void op_shift(vecs_t *V, int a, double m)
 {
     if (V->dev) { if (spike_fd_shift(V->dev, a, m)) V->err = 1; return; }
     for (I i = 0; i < V->n; ++i) V->v[a][i] -= m;
-}
-static void op_axpy(vecs_t *V, double a, int x, int y, int x2, int y2)   /* y -= a x [, y2 -= a x2] */
-{
-    if (V->dev) { if (spike_fd_axpy(V->dev, a, x, y, x2, y2)) V->err = 1; return; }
-    for (I i = 0; i < V->n; ++i) V->v[y][i] -= a * V->v[x][i];
-    if (y2 >= 0) for (I i = 0; i < V->n; ++i) V->v[y2][i] -= a * V->v[x2][i];
 }
 static void op_div(vecs_t *V, double s, int y, int y2)
 {
@@ -251,8 +232,7 @@ static void op_div(vecs_t *V, double s, int y, int y2)
 }
 static void op_update(vecs_t *V, double c0, double c1, double c2, int havep)
 {
-    if (V->dev) { if (spike_fd_update(V->dev, c0, c1, c2, havep)) V->err = 1; return; }
-    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *Lw = V->v[3], *p = V->v[4], *Lp = V->v[5];
+    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *Lw = V->v[3], *p = V->v[4], *Lp = V->v[5];   /* host vectors only */
     for (I i = 0; i < V->n; ++i) {
         const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
         const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
@@ -269,38 +249,84 @@ static void op_fill_alternating(vecs_t *V)
 static void op_deflate(vecs_t *V, int a) { const double m = op_dot(V, a, 6) / (double)V->n; op_shift(V, a, m); }
 static double op_normalize(vecs_t *V, int a) { const double s = sqrt(op_dot(V, a, a)); if (s > 0) op_div(V, s, a, -1); return s; }
 
+/* ---- fused steps: the element-wise statements of one step, then that step's sums over the UPDATED values (one host round
+ * trip each on the device; the host runs the same statements and takes the same sums) --------------------------------------- */
+static void op_resid_precond(vecs_t *V, int scale, double xn, double rho, double *sums)   /* sums: |w|^2 before precond, sum of w after */
+{
+    if (V->dev) { if (spike_fd_resid_precond(V->dev, scale, xn, rho, sums)) V->err = 1; return; }
+    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2];
+    if (scale) for (I i = 0; i < V->n; ++i) { x[i] /= xn; Lx[i] /= xn; }
+    for (I i = 0; i < V->n; ++i) w[i] = Lx[i] - rho * x[i];
+    sums[0] = dot(V->n, w, w);
+    for (I i = 0; i < V->n; ++i) w[i] /= (V->g->deg[i] > 0 ? V->g->deg[i] : 1.0);
+    sums[1] = dot(V->n, w, NULL);
+}
+static void op_shift_dots(vecs_t *V, double m, int havep, double *sums)   /* w -= m; sums: w.x, p.x */
+{
+    if (V->dev) { if (spike_fd_shift_dots(V->dev, m, havep, sums)) V->err = 1; return; }
+    for (I i = 0; i < V->n; ++i) V->v[2][i] -= m;
+    sums[0] = dot(V->n, V->v[2], V->v[0]);
+    sums[1] = havep ? dot(V->n, V->v[4], V->v[0]) : 0.0;
+}
+static void op_orth_p(vecs_t *V, double a, double b, int havep, double *sums)   /* w -= a x; p -= b x; Lp -= b Lx; sums: p.p, w.p */
+{
+    if (V->dev) { if (spike_fd_orth_p(V->dev, a, b, havep, sums)) V->err = 1; return; }
+    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *p = V->v[4], *Lp = V->v[5];
+    for (I i = 0; i < V->n; ++i) w[i] = w[i] - a * x[i];
+    sums[0] = sums[1] = 0.0;
+    if (!havep) return;
+    for (I i = 0; i < V->n; ++i) { p[i] = p[i] - b * x[i]; Lp[i] = Lp[i] - b * Lx[i]; }
+    sums[0] = dot(V->n, p, p);
+    sums[1] = dot(V->n, w, p);
+}
+static double op_orth_w(vecs_t *V, double pn, double a2, int havep)   /* p /= pn; Lp /= pn; w -= a2 p; returns w.w */
+{
+    double ww = 0.0;
+    if (V->dev) { if (spike_fd_orth_w(V->dev, pn, a2, havep, &ww)) V->err = 1; return ww; }
+    double *w = V->v[2], *p = V->v[4], *Lp = V->v[5];
+    if (havep) for (I i = 0; i < V->n; ++i) { p[i] = p[i] / pn; Lp[i] = Lp[i] / pn; w[i] = w[i] - a2 * p[i]; }
+    return dot(V->n, w, w);
+}
+static double op_update_xx(vecs_t *V, double c0, double c1, double c2, int havep)   /* Rayleigh-Ritz update; returns x.x */
+{
+    double xx = 0.0;
+    if (V->dev) { if (spike_fd_update_xx(V->dev, c0, c1, c2, havep, &xx)) V->err = 1; return xx; }
+    op_update(V, c0, c1, c2, havep);
+    return dot(V->n, V->v[0], V->v[0]);
+}
+
 /* single-vector LOBPCG for the smallest eigenpair of L restricted to the complement of the constant vector: THE iteration,
-   the same statements whichever side holds the vectors */
+   the same statements whichever side holds the vectors.  Six reductions per iteration (each a host round trip when the
+   vectors live on the device): [residual + preconditioning], [deflation + w.x, p.x], [orthogonalisation against x + p.p, w.p],
+   [normalise p, orthogonalise w against p + w.w], [the six Rayleigh-Ritz products], [update + x.x].  The Rayleigh quotient of
+   an iterate is its Ritz value (no seventh reduction); p is normalised by the scalar p.p and w's coefficient against it is
+   (w.p)/|p|; x and Lx are scaled to unit length at the start of the next iteration. */
 static void refine_core(vecs_t *V, double dmax, int maxit)
 {
     op_deflate(V, 0);
     if (op_normalize(V, 0) == 0.0) { op_fill_alternating(V); op_deflate(V, 0); op_normalize(V, 0); }
     op_lap(V, 0, 1);
-    int havep = 0;
+    int havep = 0, scale = 0;
+    double rho = op_dot(V, 0, 1), xn = 1.0;
     g_last_its = 0;
     for (int it = 0; it < maxit && !V->err; ++it) {
         g_last_its = it + 1;
-        const double rho = op_dot(V, 0, 1);
-        const double rn2 = op_resid(V, rho);
-        if (sqrt(rn2) <= 1e-9 * dmax) break;
-        { const double m = op_precond(V) / (double)V->n; op_shift(V, 2, m); }   /* w /= deg, constant vector deflated */
-        /* orthogonalise w against x (and p), normalise */
-        double a;
+        double s2[2];
+        op_resid_precond(V, scale, xn, rho, s2);
+        scale = 0;
+        if (sqrt(s2[0]) <= 1e-9 * dmax) break;
+        op_shift_dots(V, s2[1] / (double)V->n, havep, s2);       /* constant vector deflated; w.x, p.x */
+        const double a = s2[0], b = s2[1];
+        op_orth_p(V, a, b, havep, s2);                            /* against x; p.p, w.p of the results */
+        double pn = 1.0, a2 = 0.0;
         if (havep) {
-            const int ia[2] = {2, 4}, ib[2] = {0, 0};
-            double d2[2];
-            op_dots(V, 2, ia, ib, d2);             /* w.x and p.x (independent of each other) */
-            op_axpy(V, d2[0], 0, 2, -1, -1);
-            op_axpy(V, d2[1], 0, 4, 1, 5);         /* p -= a x, Lp -= a Lx */
-            const double pn = sqrt(op_dot(V, 4, 4));
-            if (pn > 1e-300) op_div(V, pn, 4, 5);
+            pn = sqrt(s2[0]);
+            if (pn > 1e-300) a2 = s2[1] / pn;
             else havep = 0;
-        } else {
-            a = op_dot(V, 2, 0);
-            op_axpy(V, a, 0, 2, -1, -1);
         }
-        if (havep) { a = op_dot(V, 2, 4); op_axpy(V, a, 4, 2, -1, -1); }
-        if (op_normalize(V, 2) < 1e-300) break;
+        const double wn = sqrt(op_orth_w(V, pn, a2, havep));
+        if (wn < 1e-300) break;
+        op_div(V, wn, 2, -1);
         op_lap(V, 2, 3);
         const int m = havep ? 3 : 2;
         double G[3][3], c[3], lam, d6[6];
@@ -316,11 +342,12 @@ static void refine_core(vecs_t *V, double dmax, int maxit)
         }
         eig3(m, G, c, &lam);
         if (c[0] < 0) for (int i = 0; i < m; ++i) c[i] = -c[i];
-        op_update(V, c[0], c[1], havep ? c[2] : 0.0, havep);
+        xn = sqrt(op_update_xx(V, c[0], c[1], havep ? c[2] : 0.0, havep));
         havep = 1;
-        const double xn = sqrt(op_dot(V, 0, 0));
-        op_div(V, xn, 0, 1);
+        scale = 1;          /* x, Lx are divided by xn at the start of the next iteration ... */
+        rho = lam;          /* ... whose Rayleigh quotient is this Ritz value */
     }
+    if (scale && !V->err) op_div(V, xn, 0, 1);   /* ... or here, after the last one */
 }
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }

@@ -55,75 +55,11 @@ __global__ __launch_bounds__(256) void k_fd_dots(DotArgs d, int64_t n, int64_t n
     }
 }
 
-// w = Lx - rho x (element-wise), chunk sums of w_i^2
-__global__ __launch_bounds__(256) void k_fd_resid(int64_t n, double rho, const double *x, const double *Lx, double *w, double *out)
-{
-#pragma clang fp contract(off)
-    __shared__ double s[256];
-    const int t = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * CH;
-    double v = 0.0;
-    for (int q = 0; q < 4; ++q) {
-        const int64_t i = c0 + t + 256 * q;
-        double p = 0.0;
-        if (i < n) {
-            const double r = Lx[i] - rho * x[i];
-            w[i] = r;
-            p = r * r;
-        }
-        v = (q == 0) ? p : v + p;
-    }
-    s[t] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) s[t] += s[t + o];
-        __syncthreads();
-    }
-    if (t == 0) out[blockIdx.x] = s[0];
-}
-
-// w_i /= (deg_i > 0 ? deg_i : 1), chunk sums of the result (the mean deflate() subtracts)
-__global__ __launch_bounds__(256) void k_fd_precond(int64_t n, const double *deg, double *w, double *out)
-{
-#pragma clang fp contract(off)
-    __shared__ double s[256];
-    const int t = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * CH;
-    double v = 0.0;
-    for (int q = 0; q < 4; ++q) {
-        const int64_t i = c0 + t + 256 * q;
-        double p = 0.0;
-        if (i < n) {
-            const double dg = deg[i];
-            p = w[i] / (dg > 0 ? dg : 1.0);
-            w[i] = p;
-        }
-        v = (q == 0) ? p : v + p;
-    }
-    s[t] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) s[t] += s[t + o];
-        __syncthreads();
-    }
-    if (t == 0) out[blockIdx.x] = s[0];
-}
-
 __global__ void k_fd_shift(int64_t n, double m, double *w)
 {
 #pragma clang fp contract(off)
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) w[i] -= m;
-}
-
-// y -= a x  (and, when y2 != null, y2 -= a x2)
-__global__ void k_fd_axpy(int64_t n, double a, const double *x, double *y, const double *x2, double *y2)
-{
-#pragma clang fp contract(off)
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    y[i] -= a * x[i];
-    if (y2 != nullptr) y2[i] -= a * x2[i];
 }
 
 // y /= s (and y2 /= s)
@@ -147,19 +83,157 @@ __global__ void k_fd_lap(int64_t n, const int64_t *xadj, const int32_t *adj, con
     y[i] = s;
 }
 
-// the Rayleigh-Ritz update of fiedler.c:refine_core: x <- c0 x + c1 w + c2 p, p <- c1 w + c2 p, same for the L-images
-__global__ void k_fd_update(int64_t n, double c0, double c1, double c2, int havep, double *x, double *Lx, const double *w,
-                            const double *Lw, double *p, double *Lp)
+// ---- fused steps of refine_core (round 2: nine host round trips per iteration -> six) ------------------------------------
+// Each kernel performs the element-wise statements of one step and accumulates that step's sums over the UPDATED values,
+// chunk by chunk in the reduction order of the spec; the host implementation runs the same statements over all elements
+// and then takes the same sums.
+struct FusedOut { double *o0, *o1; };
+
+__device__ __forceinline__ void chunk_reduce2(double v0, double v1, double *s0, double *s1, int t, FusedOut out, bool two)
+{
+    s0[t] = v0;
+    if (two) s1[t] = v1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { s0[t] += s0[t + o]; if (two) s1[t] += s1[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) { out.o0[blockIdx.x] = s0[0]; if (two) out.o1[blockIdx.x] = s1[0]; }
+}
+
+// [x /= xn, Lx /= xn]; w = Lx - rho x; sums: w^2 ; then w /= deg; sums: w
+__global__ __launch_bounds__(256) void k_fd_resid_precond(int64_t n, int scale, double xn, double rho, double *x, double *Lx,
+                                                          const double *deg, double *w, FusedOut out)
 {
 #pragma clang fp contract(off)
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
-    const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
-    x[i] = c0 * x[i] + pn;
-    Lx[i] = c0 * Lx[i] + Lpn;
-    p[i] = pn;
-    Lp[i] = Lpn;
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v0 = 0.0, v1 = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double p0 = 0.0, p1 = 0.0;
+        if (i < n) {
+            double xi = x[i], li = Lx[i];
+            if (scale) { xi /= xn; li /= xn; x[i] = xi; Lx[i] = li; }
+            const double r = li - rho * xi;
+            p0 = r * r;
+            const double dg = deg[i];
+            p1 = r / (dg > 0 ? dg : 1.0);
+            w[i] = p1;
+        }
+        v0 = (q == 0) ? p0 : v0 + p0;
+        v1 = (q == 0) ? p1 : v1 + p1;
+    }
+    chunk_reduce2(v0, v1, s0, s1, t, out, true);
+}
+
+// w -= m; sums: w.x [, p.x]
+__global__ __launch_bounds__(256) void k_fd_shift_dots(int64_t n, double m, int havep, double *w, const double *x, const double *p,
+                                                       FusedOut out)
+{
+#pragma clang fp contract(off)
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v0 = 0.0, v1 = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double p0 = 0.0, p1 = 0.0;
+        if (i < n) {
+            const double wi = w[i] - m;
+            w[i] = wi;
+            p0 = wi * x[i];
+            if (havep) p1 = p[i] * x[i];
+        }
+        v0 = (q == 0) ? p0 : v0 + p0;
+        v1 = (q == 0) ? p1 : v1 + p1;
+    }
+    chunk_reduce2(v0, v1, s0, s1, t, out, havep != 0);
+}
+
+// w -= a x; [p -= b x; Lp -= b Lx; sums: p.p, w.p]
+__global__ __launch_bounds__(256) void k_fd_orth_p(int64_t n, double a, double b, int havep, double *w, const double *x,
+                                                   const double *Lx, double *p, double *Lp, FusedOut out)
+{
+#pragma clang fp contract(off)
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v0 = 0.0, v1 = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double p0 = 0.0, p1 = 0.0;
+        if (i < n) {
+            const double wi = w[i] - a * x[i];
+            w[i] = wi;
+            if (havep) {
+                const double pi = p[i] - b * x[i];
+                p[i] = pi;
+                Lp[i] = Lp[i] - b * Lx[i];
+                p0 = pi * pi;
+                p1 = wi * pi;
+            }
+        }
+        v0 = (q == 0) ? p0 : v0 + p0;
+        v1 = (q == 0) ? p1 : v1 + p1;
+    }
+    if (havep) chunk_reduce2(v0, v1, s0, s1, t, out, true);
+}
+
+// [p /= pn; Lp /= pn; w -= a2 p]; sums: w.w
+__global__ __launch_bounds__(256) void k_fd_orth_w(int64_t n, double pn, double a2, int havep, double *w, double *p, double *Lp,
+                                                   FusedOut out)
+{
+#pragma clang fp contract(off)
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v0 = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double p0 = 0.0;
+        if (i < n) {
+            double wi = w[i];
+            if (havep) {
+                const double pi = p[i] / pn;
+                p[i] = pi;
+                Lp[i] = Lp[i] / pn;
+                wi = wi - a2 * pi;
+                w[i] = wi;
+            }
+            p0 = wi * wi;
+        }
+        v0 = (q == 0) ? p0 : v0 + p0;
+    }
+    chunk_reduce2(v0, 0.0, s0, s1, t, out, false);
+}
+
+// Rayleigh-Ritz update; sums: x.x of the new x
+__global__ __launch_bounds__(256) void k_fd_update_xx(int64_t n, double c0_, double c1, double c2, int havep, double *x, double *Lx,
+                                                      const double *w, const double *Lw, double *p, double *Lp, FusedOut out)
+{
+#pragma clang fp contract(off)
+    __shared__ double s0[256], s1[256];
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v0 = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double p0 = 0.0;
+        if (i < n) {
+            const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
+            const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
+            const double xi = c0_ * x[i] + pn;
+            x[i] = xi;
+            Lx[i] = c0_ * Lx[i] + Lpn;
+            p[i] = pn;
+            Lp[i] = Lpn;
+            p0 = xi * xi;
+        }
+        v0 = (q == 0) ? p0 : v0 + p0;
+    }
+    chunk_reduce2(v0, 0.0, s0, s1, t, out, false);
 }
 
 __global__ void k_fd_fill_one(int64_t n, double *x)
@@ -265,51 +339,20 @@ extern "C" int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *
     return SPIKE_OK;
 }
 
-static int chunk_total(spike_fd_ctx *c, double *tot)
-{
-    FDCHK(hipMemcpyAsync(c->hchunk, c->dchunk, sizeof(double) * (size_t)c->nchunks, hipMemcpyDeviceToHost, c->st));
-    FDCHK(hipStreamSynchronize(c->st));
-    double t = 0.0;
-    for (int64_t q = 0; q < c->nchunks; ++q) t += c->hchunk[q];
-    *tot = t;
-    return SPIKE_OK;
-}
 
 extern "C" int spike_fd_lap(spike_fd_ctx *c, int src, int dst)   // v[dst] = L v[src]
 {
     hipLaunchKernelGGL(k_fd_lap, grid1(c->n), dim3(256), 0, c->st, c->n, c->xadj, c->adj, c->w_e, c->deg, c->v[src], c->v[dst]);
     return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
 }
-extern "C" int spike_fd_resid(spike_fd_ctx *c, double rho, double *rn2)   // w = Lx - rho x; rn2 = sum w^2
-{
-    hipLaunchKernelGGL(k_fd_resid, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, rho, c->v[0], c->v[1], c->v[2], c->dchunk);
-    return chunk_total(c, rn2);
-}
-extern "C" int spike_fd_precond(spike_fd_ctx *c, double *sum)   // w /= deg; sum = sum w
-{
-    hipLaunchKernelGGL(k_fd_precond, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, c->deg, c->v[2], c->dchunk);
-    return chunk_total(c, sum);
-}
 extern "C" int spike_fd_shift(spike_fd_ctx *c, int vec, double m)   // v -= m
 {
     hipLaunchKernelGGL(k_fd_shift, grid1(c->n), dim3(256), 0, c->st, c->n, m, c->v[vec]);
     return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
 }
-extern "C" int spike_fd_axpy(spike_fd_ctx *c, double a, int x, int y, int x2, int y2)   // y -= a x [, y2 -= a x2]; x2 < 0: none
-{
-    hipLaunchKernelGGL(k_fd_axpy, grid1(c->n), dim3(256), 0, c->st, c->n, a, c->v[x], c->v[y], x2 >= 0 ? c->v[x2] : nullptr,
-                       y2 >= 0 ? c->v[y2] : nullptr);
-    return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
-}
 extern "C" int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2)   // y /= s [, y2 /= s]
 {
     hipLaunchKernelGGL(k_fd_div, grid1(c->n), dim3(256), 0, c->st, c->n, s, c->v[y], y2 >= 0 ? c->v[y2] : nullptr);
-    return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
-}
-extern "C" int spike_fd_update(spike_fd_ctx *c, double c0, double c1, double c2, int havep)
-{
-    hipLaunchKernelGGL(k_fd_update, grid1(c->n), dim3(256), 0, c->st, c->n, c0, c1, c2, havep, c->v[0], c->v[1], c->v[2], c->v[3],
-                       c->v[4], c->v[5]);
     return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
 }
 extern "C" int spike_fd_fill_alternating(spike_fd_ctx *c)   // x_i = (i odd ? 1 : -1)
@@ -322,4 +365,52 @@ extern "C" int spike_fd_download_x(spike_fd_ctx *c, double *x)
     FDCHK(hipMemcpyAsync(x, c->v[0], sizeof(double) * (size_t)c->n, hipMemcpyDeviceToHost, c->st));
     FDCHK(hipStreamSynchronize(c->st));
     return SPIKE_OK;
+}
+
+// ---- fused steps (see the kernels): sums[0..1] in the reduction order of the spec ------------------------------------------
+static int two_totals(spike_fd_ctx *c, int nsum, double *sums)
+{
+    FDCHK(hipMemcpyAsync(c->hchunk, c->dchunk, sizeof(double) * (size_t)(nsum * c->nchunks), hipMemcpyDeviceToHost, c->st));
+    FDCHK(hipStreamSynchronize(c->st));
+    for (int j = 0; j < nsum; ++j) {
+        double t = 0.0;
+        for (int64_t q = 0; q < c->nchunks; ++q) t += c->hchunk[(int64_t)j * c->nchunks + q];
+        sums[j] = t;
+    }
+    return SPIKE_OK;
+}
+#define FD_OUT(c) FusedOut{(c)->dchunk, (c)->dchunk + (c)->nchunks}
+
+extern "C" int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums /* rn2, sum w */)
+{
+    hipLaunchKernelGGL(k_fd_resid_precond, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, scale, xn, rho, c->v[0], c->v[1],
+                       c->deg, c->v[2], FD_OUT(c));
+    return two_totals(c, 2, sums);
+}
+extern "C" int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums /* w.x, p.x */)
+{
+    hipLaunchKernelGGL(k_fd_shift_dots, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, m, havep, c->v[2], c->v[0], c->v[4],
+                       FD_OUT(c));
+    sums[1] = 0.0;
+    return two_totals(c, havep ? 2 : 1, sums);
+}
+extern "C" int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums /* p.p, w.p */)
+{
+    hipLaunchKernelGGL(k_fd_orth_p, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, a, b, havep, c->v[2], c->v[0], c->v[1],
+                       c->v[4], c->v[5], FD_OUT(c));
+    sums[0] = sums[1] = 0.0;
+    if (!havep) return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
+    return two_totals(c, 2, sums);
+}
+extern "C" int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww)
+{
+    hipLaunchKernelGGL(k_fd_orth_w, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, pn, a2, havep, c->v[2], c->v[4], c->v[5],
+                       FD_OUT(c));
+    return two_totals(c, 1, ww);
+}
+extern "C" int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx)
+{
+    hipLaunchKernelGGL(k_fd_update_xx, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, c0, c1, c2, havep, c->v[0], c->v[1],
+                       c->v[2], c->v[3], c->v[4], c->v[5], FD_OUT(c));
+    return two_totals(c, 1, xx);
 }

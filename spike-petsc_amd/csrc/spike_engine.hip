@@ -789,8 +789,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->nboost = (int64_t)nb;
-    tmp.release(dLU);
-    tmp.release(dScal);
+    // (the LU scratch stays alive until the spike columns are done: the block-TRSM reads the factors in their tile form)
 
     mark("pack");
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
@@ -939,15 +938,29 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         mark("sub-chain descriptors");
         // The 2K spike columns are solved sweep_multi_nr(cfg) at a time (k_sweep_multi: a factor tile is read once for the
         // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
+        // Spike columns.  32 < K <= 128 with decayed spikes (partial) and chain lengths that are multiples of 16: all K
+        // columns at once by the blocked banded TRSM on MFMA over the dense LU tiles (k_spike_trsm); otherwise as
+        // right-hand sides of the sweep kernels, a few columns per pass over the packed factors.
+        bool trsm = partial && lu_blk != 0 && K <= 128 && getenv("SPIKE_NO_TRSM") == nullptr;
+        for (int p = 0; p < P && trsm; ++p) trsm = h->chains[p].nrows % 16 == 0;
+        if (trsm) {
+            const int region = ((m + K + cfg.R - 1) / cfg.R + 1) * cfg.R;   // the same rows the sweep-based partial solves cover
+            double *dZ = nullptr;
+            HIPCHK(tmp.alloc(&dZ, spike_trsm_scratch_doubles(K, P, region)));
+            HIPCHK(launch_spike_trsm(dLU, K, m, region, h->dChains, P, h->dA, h->ldA, n_global, row0, h->dWt, h->dVb, h->dWf, h->dVf,
+                                     dZ, dStat, dStat + 1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            tmp.release(dZ);
+        }
         const bool batched = cfg.R == 64 && !cfg.scan;
         const int NRB = batched ? sweep_multi_nr(cfg) : 1;
         double *rhsM = rhs, *solM = sol, *midM = h->dY;
-        if (batched) {
+        if (batched && !trsm) {
             HIPCHK(tmp.alloc(&rhsM, (size_t)NRB * n));
             HIPCHK(tmp.alloc(&solM, (size_t)NRB * n));
             HIPCHK(tmp.alloc(&midM, (size_t)NRB * n));
         }
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 2 && !trsm; ++which) {
             HIPCHK(hipMemsetAsync(rhsM, 0, sizeof(double) * n * NRB, st));
             const SubChains *sub = partial ? (which == 0 ? &subTop : &subBot) : nullptr;
             for (int col = 0; col < K; col += NRB) {
@@ -969,7 +982,9 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 if (m > 0) HIPCHK(launch_spike_gather(solM, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st, nc, n));
             }
         }
-        if (batched) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
+        if (batched && !trsm) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
+        HIPCHK(hipStreamSynchronize(st));
+        tmp.release(dLU);
         mark("spike solves");
         h->profile = keep_prof;
         if (m > 0) {

@@ -125,6 +125,13 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0);
 
+// spike columns by the blocked banded TRSM on MFMA (32 < K <= 128, chain lengths multiples of 16): reads the block-band LU
+// scratch `lu` (after launch_factor), fills the tips Wt / Vb, the stored spikes Wf / Vf (m rows, may be null with m = 0) and
+// the two extrema the caller checks the decay with; region = rows solved next to every interface (multiple of 64)
+size_t spike_trsm_scratch_doubles(int K, int nchains, int region);
+hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
+                             int64_t ld, int64_t n_global, int64_t grow0, double *Wt, double *Vb, double *Wf, double *Vf,
+                             double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st);
 hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hipStream_t st);
 
 // Krylov pieces (spike_krylov.hip)

@@ -2096,6 +2096,234 @@ hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t
 }
 
 // ------------------------------------------------------------------------------------------
+// k_spike_trsm: the 2K spike columns of every chain by a blocked banded triangular solve on MFMA (round 2).
+// Round 1/2a solved them as right-hand sides of the SWEEP kernels, 2-4 columns per pass over the packed factors: 32-64
+// passes, each bound by the per-column LDS window traffic (19-21 ms at the headline size).  Here the factors are read in
+// their dense 16 x 16 tile form (the block-band LU scratch, still alive at this point of setup) and ALL K columns go
+// through at once: workgroup = (chain, side), wave = 16 columns, and a wave needs nobody else --
+//   forward   Z_rb = L_rb,rb^{-1} (R_rb - sum_{d=1..KB} L_rb,rb-d Z_rb-d)          row blocks of 16, top to bottom
+//   backward  X_rb = U_rb,rb^{-1} (Z_rb - sum_{d=1..KB} U_rb,rb+d X_rb+d)          bottom to top
+// with the products on v_mfma_f64_16x16x4: A operand = factor tile straight from the scratch (L2), B operand = the last KB
+// solved tiles, which stay in REGISTERS (the C/D layout of the instruction is its B layout), the 16 x 16 triangular solve
+// with the diagonal tile by 16 lanes through a 2-KiB LDS tile (which also transposes the result for the column-major
+// spike store).  Z goes through a scratch area in tile form (written once, read once).  Side 0 = W (right-hand side
+// C_p in the top K rows, region = the first `region` rows: exact forward, backward started where the spike is below
+// rounding), side 1 = V (B_p in the bottom K rows, region = the last `region` rows: the forward sweep starts at the block
+// that holds row nrows-K, exact; backward from the chain end, exact).  Same truncation as the sweep-based solves.
+// Needs K <= 128 (window of KB <= 8 tiles per wave) and every chain length a multiple of 16.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_pos(double *addr, double v);
+
+struct TrsmArgs {
+    LuView lv;
+    const ChainDesc *chains;
+    const double *band;      // kept band (diagonal-major): coupling blocks C, B for the right-hand sides
+    int64_t ld, n_global, grow0;
+    int K, m, region;        // region = rows solved next to the interface (multiple of 64)
+    double *Wt, *Vb;         // tips, row-major K x K per chain
+    double *Wf, *Vf;         // stored spikes, column-major K x m per chain (may be null when m == 0)
+    double *zscratch;        // per (chain, side, wave): region/16 tiles of 256 doubles
+    double *absmax_in, *absmax_edge;
+};
+
+template <int KB>
+__global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
+{
+    constexpr int TL = 17;                       // LDS tile row stride
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    double *tb = lds + w * 2 * 16 * TL;          // this wave's working tile [row][col]
+    double *dt = tb + 16 * TL;                   // the diagonal factor tile
+    const int p = blockIdx.x, side = blockIdx.y;
+    const ChainDesc cd = a.chains[p];
+    const int K = a.K, m = a.m;
+    const int np = cd.nrows;
+    const bool on = side == 0 ? (a.grow0 + cd.row0 > 0) : (a.grow0 + cd.row0 + np < a.n_global);
+    const int c0 = 16 * w;                       // this wave's columns c0 .. c0+15
+    double *tips = (side == 0 ? a.Wt : a.Vb) + (int64_t)p * K * K;
+    if (!on) {                                   // no neighbour on this side: the tips stay zero (setup cleared them)
+        return;
+    }
+    const int region = a.region < np ? a.region : np;
+    const int NB = region / 16;
+    const int rb0 = side == 0 ? 0 : (np - region) / 16;        // first row block of the region (chain-local)
+    const int rbs = side == 0 ? 0 : (np - K) / 16 - rb0;       // first region block with a nonzero right-hand side
+    const int64_t rbg0 = (cd.row0 >> 4) + rb0;
+    const LuView lv = a.lv;
+    double *zs = a.zscratch + (((int64_t)p * 2 + side) * nwv + w) * (int64_t)NB * 256;
+    const int li = lane & 15, lk = lane >> 4;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    auto tile_ptr = [&](int rb, int slot) -> const double * { return lv.p + ((rbg0 + rb) * lv.ntl + slot) * 256; };
+
+    v4 Xw[KB];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
+
+    // right-hand side tile of region block rb in D layout (row = lk + 4r, col = li)
+    auto rhs_tile = [&](int rb) -> v4 {
+        v4 t = {0.0, 0.0, 0.0, 0.0};
+        const int col = c0 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (rb0 + rb) * 16 + lk + 4 * r;       // chain-local row
+            double v = 0.0;
+            if (col < K) {
+                if (side == 0) {                                // C_p(a, b) = A[s+a, s-K+b], a = row < K, nonzero for a <= b
+                    if (row < K && row <= col) v = a.band[(int64_t)(col - row) * a.ld + cd.row0 + row];
+                } else {                                        // B_p(a, b) = A[e-K+a, e+b], a = row-(np-K) >= 0, nonzero for b <= a
+                    const int aa = row - (np - K);
+                    if (aa >= 0 && col <= aa) v = a.band[(int64_t)(2 * K + col - aa) * a.ld + cd.row0 + row];
+                }
+            }
+            t[r] = v;
+        }
+        return t;
+    };
+    // acc -= F(rb, slot) * B for one factor tile (A operand straight from the scratch)
+    auto gemm_sub = [&](v4 acc, int rb, int slot, const v4 &B) -> v4 {
+        const double *tp = tile_ptr(rb, slot) + li * 16 + lk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-tp[4 * q], B[q], acc, 0, 0, 0);
+        return acc;
+    };
+    auto put_tile = [&](const v4 &t, double *T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(lk + 4 * r) * TL + li] = t[r];
+    };
+    auto get_tile = [&](const double *T) -> v4 {
+        v4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = T[(lk + 4 * r) * TL + li];
+        return t;
+    };
+    auto load_diag = [&](int rb) {   // diagonal factor tile (rb, rb) -> dt
+        const double *tp = tile_ptr(rb, lv.KB) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dt[(lk + 4 * q) * TL + li] = tp[64 * q];
+    };
+
+    // ---------------- forward: Z ----------------
+    // (the row-block loop is unrolled by KB so that the window slot of a block, rb % KB, is a compile-time register index)
+    for (int rbb = rbs - rbs % KB; rbb < NB; rbb += KB) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int rb = rbb + u;
+            if (rb < rbs || rb >= NB) continue;
+            v4 acc = rhs_tile(rb);
+#pragma unroll
+            for (int d = 1; d <= KB; ++d)
+                if (rb - d >= rbs) acc = gemm_sub(acc, rb, lv.KB - d, Xw[(u - d + KB) % KB]);
+            put_tile(acc, tb);
+            load_diag(rb);
+            WAVE_LDS_FENCE();
+            if (lane < 16) {             // unit lower 16 x 16: column `lane` of the right-hand side tile
+                double z[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    double v = tb[i * TL + lane];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) v = fma(-dt[i * TL + k], z[k], v);
+                    z[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tb[i * TL + lane] = z[i];
+            }
+            WAVE_LDS_FENCE();
+            const v4 Z = get_tile(tb);
+            Xw[u] = Z;
+            double *zp = zs + (int64_t)rb * 256 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zp[64 * q] = Z[q];          // D layout, element lane + 64 q
+            WAVE_LDS_FENCE();
+        }
+    }
+    // ---------------- backward: X ----------------
+#pragma unroll
+    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
+    double mi = 0.0, mo = 0.0;
+    double *spike = (side == 0 ? a.Wf : a.Vf);
+    for (int rbb = ((NB - 1) / KB) * KB; rbb >= 0; rbb -= KB) {
+#pragma unroll
+        for (int u = KB - 1; u >= 0; --u) {
+            const int rb = rbb + u;
+            if (rb >= NB) continue;
+            v4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (rb >= rbs) {
+                const double *zp = zs + (int64_t)rb * 256 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = zp[64 * q];
+            }
+#pragma unroll
+            for (int d = 1; d <= KB; ++d)
+                if (rb + d < NB) acc = gemm_sub(acc, rb, lv.KB + d, Xw[(u + d) % KB]);
+            put_tile(acc, tb);
+            load_diag(rb);
+            WAVE_LDS_FENCE();
+            if (lane < 16) {             // upper 16 x 16 with its diagonal
+                double x[16];
+#pragma unroll
+                for (int i = 15; i >= 0; --i) {
+                    double v = tb[i * TL + lane];
+#pragma unroll
+                    for (int k = i + 1; k < 16; ++k) v = fma(-dt[i * TL + k], x[k], v);
+                    x[i] = v / dt[i * TL + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tb[i * TL + lane] = x[i];
+            }
+            WAVE_LDS_FENCE();
+            Xw[u] = get_tile(tb);
+            // ---- outputs: lane = (column li, rows 4 lk .. 4 lk + 3 of the block)
+            const int col = c0 + li;
+            if (col < K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (rb0 + rb) * 16 + 4 * lk + e;    // chain-local row
+                    const double v = tb[(4 * lk + e) * TL + li];
+                    const int dist = side == 0 ? row : np - 1 - row; // rows from the interface
+                    if (dist < K) tips[(int64_t)(side == 0 ? row : row - (np - K)) * K + col] = v;
+                    if (spike != nullptr && dist < m) {
+                        spike[((int64_t)p * K + col) * m + (side == 0 ? row : row - (np - m))] = v;
+                        mi = fmax(mi, fabs(v));
+                        if (dist >= m - 32) mo = fmax(mo, fabs(v));
+                    }
+                }
+            }
+            WAVE_LDS_FENCE();
+        }
+    }
+    if (spike != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
+        if (lane == 0) {
+            if (mi > __hip_atomic_load(a.absmax_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_in, mi);
+            if (mo > __hip_atomic_load(a.absmax_edge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_edge, mo);
+        }
+    }
+}
+
+// doubles of Z scratch launch_spike_trsm needs
+size_t spike_trsm_scratch_doubles(int K, int nchains, int region) { return (size_t)nchains * 2 * ((K + 15) / 16) * (size_t)(region / 16) * 256; }
+
+hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
+                             int64_t ld, int64_t n_global, int64_t grow0, double *Wt, double *Vb, double *Wf, double *Vf,
+                             double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 32 || K > 128) return hipErrorInvalidValue;
+    TrsmArgs a;
+    a.lv.p = lu; a.lv.ld = 0; a.lv.K = K; a.lv.KB = lu_kb(K); a.lv.ntl = 2 * a.lv.KB + 1;
+    a.chains = chains; a.band = band; a.ld = ld; a.n_global = n_global; a.grow0 = grow0;
+    a.K = K; a.m = m; a.region = region; a.Wt = Wt; a.Vb = Vb; a.Wf = Wf; a.Vf = Vf; a.zscratch = zscratch;
+    a.absmax_in = absmax_in; a.absmax_edge = absmax_edge;
+    const int nwv = (K + 15) / 16;
+    const size_t shm = (size_t)nwv * 2 * 16 * 17 * sizeof(double);
+    if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm<4>, dim3(nchains, 2), dim3(nwv * 64), shm, st, a);
+    else hipLaunchKernelGGL(k_spike_trsm<8>, dim3(nchains, 2), dim3(nwv * 64), shm, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // interface systems
 // ------------------------------------------------------------------------------------------
 // work: per interface K x 2K row-major [S | I] -> [I | S^{-1}] by Gauss-Jordan with partial pivoting

@@ -938,10 +938,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         mark("sub-chain descriptors");
         // The 2K spike columns are solved sweep_multi_nr(cfg) at a time (k_sweep_multi: a factor tile is read once for the
         // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
-        // Spike columns.  32 < K <= 128 with decayed spikes (partial) and chain lengths that are multiples of 16: all K
+        // Spike columns.  K > 32 with decayed spikes (partial) and chain lengths that are multiples of 16: all K
         // columns at once by the blocked banded TRSM on MFMA over the dense LU tiles (k_spike_trsm); otherwise as
         // right-hand sides of the sweep kernels, a few columns per pass over the packed factors.
-        bool trsm = partial && lu_blk != 0 && K <= 128 && getenv("SPIKE_NO_TRSM") == nullptr;
+        bool trsm = partial && lu_blk != 0 && getenv("SPIKE_NO_TRSM") == nullptr;
         for (int p = 0; p < P && trsm; ++p) trsm = h->chains[p].nrows % 16 == 0;
         if (trsm) {
             const int region = ((m + K + cfg.R - 1) / cfg.R + 1) * cfg.R;   // the same rows the sweep-based partial solves cover

@@ -2134,6 +2134,8 @@ __global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwv = blockDim.x >> 6;
+    const int wg = w + nwv * blockIdx.z;         // column tile of this wave (K > 128: two workgroups of 8 waves share a chain side)
+    const int ncw = nwv * gridDim.z;
     double *tb = lds + w * 2 * 16 * TL;          // this wave's working tile [row][col]
     double *dt = tb + 16 * TL;                   // the diagonal factor tile
     const int p = blockIdx.x, side = blockIdx.y;
@@ -2141,7 +2143,7 @@ __global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
     const int K = a.K, m = a.m;
     const int np = cd.nrows;
     const bool on = side == 0 ? (a.grow0 + cd.row0 > 0) : (a.grow0 + cd.row0 + np < a.n_global);
-    const int c0 = 16 * w;                       // this wave's columns c0 .. c0+15
+    const int c0 = 16 * wg;                      // this wave's columns c0 .. c0+15
     double *tips = (side == 0 ? a.Wt : a.Vb) + (int64_t)p * K * K;
     if (!on) {                                   // no neighbour on this side: the tips stay zero (setup cleared them)
         return;
@@ -2152,7 +2154,7 @@ __global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
     const int rbs = side == 0 ? 0 : (np - K) / 16 - rb0;       // first region block with a nonzero right-hand side
     const int64_t rbg0 = (cd.row0 >> 4) + rb0;
     const LuView lv = a.lv;
-    double *zs = a.zscratch + (((int64_t)p * 2 + side) * nwv + w) * (int64_t)NB * 256;
+    double *zs = a.zscratch + (((int64_t)p * 2 + side) * ncw + wg) * (int64_t)NB * 256;
     const int li = lane & 15, lk = lane >> 4;
     typedef double v4 __attribute__((ext_vector_type(4)));
     auto tile_ptr = [&](int rb, int slot) -> const double * { return lv.p + ((rbg0 + rb) * lv.ntl + slot) * 256; };
@@ -2304,22 +2306,28 @@ __global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
 }
 
 // doubles of Z scratch launch_spike_trsm needs
-size_t spike_trsm_scratch_doubles(int K, int nchains, int region) { return (size_t)nchains * 2 * ((K + 15) / 16) * (size_t)(region / 16) * 256; }
+size_t spike_trsm_scratch_doubles(int K, int nchains, int region)
+{
+    const int nz = K > 128 ? 2 : 1, nwv = ((K + nz - 1) / nz + 15) / 16;
+    return (size_t)nchains * 2 * (size_t)(nwv * nz) * (size_t)(region / 16) * 256;
+}
 
 hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
                              int64_t ld, int64_t n_global, int64_t grow0, double *Wt, double *Vb, double *Wf, double *Vf,
                              double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st)
 {
-    if (nchains <= 0 || K <= 32 || K > 128) return hipErrorInvalidValue;
+    if (nchains <= 0 || K <= 32 || K > 256) return hipErrorInvalidValue;
     TrsmArgs a;
     a.lv.p = lu; a.lv.ld = 0; a.lv.K = K; a.lv.KB = lu_kb(K); a.lv.ntl = 2 * a.lv.KB + 1;
     a.chains = chains; a.band = band; a.ld = ld; a.n_global = n_global; a.grow0 = grow0;
     a.K = K; a.m = m; a.region = region; a.Wt = Wt; a.Vb = Vb; a.Wf = Wf; a.Vf = Vf; a.zscratch = zscratch;
     a.absmax_in = absmax_in; a.absmax_edge = absmax_edge;
-    const int nwv = (K + 15) / 16;
+    const int nz = K > 128 ? 2 : 1;                       // K > 128: the columns of a chain side over two workgroups
+    const int nwv = ((K + nz - 1) / nz + 15) / 16;        // waves per workgroup (<= 8): 16 columns each
     const size_t shm = (size_t)nwv * 2 * 16 * 17 * sizeof(double);
-    if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm<4>, dim3(nchains, 2), dim3(nwv * 64), shm, st, a);
-    else hipLaunchKernelGGL(k_spike_trsm<8>, dim3(nchains, 2), dim3(nwv * 64), shm, st, a);
+    if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm<4>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
+    else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm<8>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
+    else hipLaunchKernelGGL(k_spike_trsm<16>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
     return hipGetLastError();
 }
 

@@ -462,6 +462,17 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // 0.172-0.181 ms per apply (half the CUs idle), 512 chains 0.138, 1024 chains 0.162 (twice the spike traffic)
     if (cfg.R == 32) minrows = (int64_t)64 * K;
     if (minrows < 512) minrows = 512;
+    // Short systems (strong scaling: N/G rows per GPU) with one chain per workgroup: 32 K rows per chain would leave CUs
+    // without a chain, and ~128 busy CUs are the least that saturate HBM (tools/cu_bw_probe.hip).  A chain may then be as
+    // short as two spike windows of a dominant system (2 x 11 K rows) plus a block -- the windows must not overlap.
+    // Measured at N = 512 Ki, K = 128 (ms per apply): 128 chains of 4096 rows 0.297, 182 chains of 2880 rows see DESIGN 5.
+    if (cfg.R == 64 && !cfg.scan) {
+        const int64_t target_wg = (int64_t)ncu_dev * ((4 + cfg.NW - 1) / cfg.NW);
+        if (n / minrows < target_wg) {
+            const int64_t tight = (int64_t)22 * K + 64 + 63;
+            minrows = std::max<int64_t>(tight / 64 * 64, std::min<int64_t>(minrows, n / target_wg > 0 ? n / target_wg : minrows));
+        }
+    }
     // Workgroups in whole multiples of the CU count (balance), at least 4 waves per CU (two tiles in flight per wave
     // already cover the memory latency).  Every interface costs spike and interface traffic, so FEWER chains is
     // better as long as the sweeps stay at full bandwidth -- measured at N = 4M (ms per coupled apply, half / this many

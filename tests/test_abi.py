@@ -68,6 +68,7 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(96, N) == 512
     assert L.spike_auto_partitions(32, N) == 2048          # 2 chains per wave, 1024 one-wave workgroups
     assert L.spike_auto_partitions(1, 2 ** 24) == 8192     # scan path
-    assert L.spike_auto_partitions(128, 32768) == 8        # small systems: a partition keeps >= 32 K rows
+    assert L.spike_auto_partitions(128, 32768) == 11       # short systems: a chain may be as short as two spike windows + a block
+    assert L.spike_auto_partitions(128, 524288) == 182     # N/8 rows per GPU of the headline: 182 chains of 2880 rows, not 128 of 4096
     assert L.spike_auto_partitions(32, 2 ** 20) == 512     # BASELINE config 2: a chain keeps >= 64 K rows (measured: 512 chains 0.138 ms, 1024 0.162)
     assert L.spike_auto_partitions(300, N) < 0             # K > 256 is refused

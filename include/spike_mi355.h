@@ -210,12 +210,10 @@ int spike_fd_dots(spike_fd_ctx *c, int nd, const int *ia, const int *ib, double 
 int spike_fd_lap(spike_fd_ctx *c, int src, int dst);                                    /* v[dst] = L v[src]   */
 int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
 int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
-/* fused steps of the iteration (element-wise statements, then the step's sums over the updated values) */
-int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums); /* |w|^2, sum w  */
-int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums);                 /* w.x, p.x      */
-int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums);           /* p.p, w.p      */
-int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww);
-int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx);
+/* a level's whole LOBPCG loop: maxit x (six vector kernels, each followed by a one-thread scalar step that is the SAME C
+ * code the host loop runs, csrc/host/fiedler_steer.h), the iteration state in device memory, launched without a host
+ * round trip; steps after the stopping test fired are no-ops.  rho = x.Lx of the start vector; its = iterations run. */
+int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int maxit, int *its);
 int spike_fd_fill_alternating(spike_fd_ctx *c);
 int spike_fd_download_x(spike_fd_ctx *c, double *x);
 

@@ -33,8 +33,7 @@ ABI_SYMBOLS = [
     "spike_set_operator_band", "spike_operator_matvec", "spike_auto_partitions",
     "spike_setup_csr_dist", "spike_csr_band_weights", "spike_band_rule",
     "spike_device_count", "spike_fd_create", "spike_fd_destroy", "spike_fd_dots", "spike_fd_lap", "spike_fd_shift",
-    "spike_fd_div", "spike_fd_fill_alternating", "spike_fd_download_x", "spike_fd_resid_precond", "spike_fd_shift_dots",
-    "spike_fd_orth_p", "spike_fd_orth_w", "spike_fd_update_xx",
+    "spike_fd_div", "spike_fd_fill_alternating", "spike_fd_download_x", "spike_fd_refine",
 ]
 
 

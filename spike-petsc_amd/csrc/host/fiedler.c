@@ -82,40 +82,7 @@ static double dot(I n, const double *a, const double *b)
     return total;
 }
 
-/* cyclic Jacobi for a dense symmetric matrix (n <= ~64): eigenvalues in ev, eigenvectors in columns of V */
-static void jacobi_eig(int n, double *A, double *V, double *ev)
-{
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
-    for (int sweep = 0; sweep < 100; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
-        if (off < 1e-30) break;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - s * vkq;
-                    V[k * n + q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    for (int i = 0; i < n; ++i) ev[i] = A[i * n + i];
-}
+#include "fiedler_steer.h"   /* fd_jacobi_eig, fd_eig3, fd_state and the scalar steps of the iteration: shared with the device build */
 
 /* heavy-edge matching coarsening; returns coarse graph and fine->coarse map (malloc'd) */
 static I *coarsen(const graph_t *g, graph_t *c)
@@ -168,21 +135,10 @@ static I *coarsen(const graph_t *g, graph_t *c)
     return map;
 }
 
-static void eig3(int m, double G[3][3], double c[3], double *lam)
-{
-    double A[9], V[9], ev[3];
-    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) A[i * m + j] = G[i][j];
-    jacobi_eig(m, A, V, ev);
-    int b = 0;
-    for (int i = 1; i < m; ++i) if (ev[i] < ev[b]) b = i;
-    for (int i = 0; i < m; ++i) c[i] = V[i * m + b];
-    *lam = ev[b];
-}
-
 /* ---- the vectors of one refinement and the operations the iteration is written in ------------------------------------------
  * ids: 0 x, 1 Lx, 2 w, 3 Lw, 4 p, 5 Lp, 6 the constant 1.  Two implementations: host arrays (below) and the device
  * (spike_fd_* of libspike_mi355.so); both execute the same IEEE operations in the same order. */
-#define FD_DEVICE_MIN 12288   /* smaller levels are launch-latency bound on the device (~0.2 ms per iteration whatever n; the host needs ~17 ns per vertex and iteration); the result is the same either way */
+#define FD_DEVICE_MIN 4096    /* smaller levels: the device needs ~60-80 us per iteration whatever n (14 dependent launches), the host ~17 ns per vertex and iteration; the result is the same either way */
 static int g_last_its = 0;   /* SPIKE_FIEDLER_TRACE only */
 typedef struct spike_fd_ctx spike_fd_ctx;
 int spike_device_count(void);
@@ -194,11 +150,7 @@ int spike_fd_shift(spike_fd_ctx *c, int vec, double m);
 int spike_fd_div(spike_fd_ctx *c, double s, int y, int y2);
 int spike_fd_fill_alternating(spike_fd_ctx *c);
 int spike_fd_download_x(spike_fd_ctx *c, double *x);
-int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums);
-int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums);
-int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums);
-int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww);
-int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx);
+int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int maxit, int *its);
 
 typedef struct {
     const graph_t *g;
@@ -230,17 +182,6 @@ static void op_div(vecs_t *V, double s, int y, int y2)
     for (I i = 0; i < V->n; ++i) V->v[y][i] /= s;
     if (y2 >= 0) for (I i = 0; i < V->n; ++i) V->v[y2][i] /= s;
 }
-static void op_update(vecs_t *V, double c0, double c1, double c2, int havep)
-{
-    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *Lw = V->v[3], *p = V->v[4], *Lp = V->v[5];   /* host vectors only */
-    for (I i = 0; i < V->n; ++i) {
-        const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
-        const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
-        x[i] = c0 * x[i] + pn;
-        Lx[i] = c0 * Lx[i] + Lpn;
-        p[i] = pn; Lp[i] = Lpn;
-    }
-}
 static void op_fill_alternating(vecs_t *V)
 {
     if (V->dev) { if (spike_fd_fill_alternating(V->dev)) V->err = 1; return; }
@@ -249,105 +190,98 @@ static void op_fill_alternating(vecs_t *V)
 static void op_deflate(vecs_t *V, int a) { const double m = op_dot(V, a, 6) / (double)V->n; op_shift(V, a, m); }
 static double op_normalize(vecs_t *V, int a) { const double s = sqrt(op_dot(V, a, a)); if (s > 0) op_div(V, s, a, -1); return s; }
 
-/* ---- fused steps: the element-wise statements of one step, then that step's sums over the UPDATED values (one host round
- * trip each on the device; the host runs the same statements and takes the same sums) --------------------------------------- */
-static void op_resid_precond(vecs_t *V, int scale, double xn, double rho, double *sums)   /* sums: |w|^2 before precond, sum of w after */
+/* ---- the vector steps of one iteration, host implementation: the element-wise statements of the step over all elements,
+ * then that step's sums over the UPDATED values (device implementation: k_fd_* in spike_fiedler.hip, the same statements
+ * chunk by chunk).  Scalars come from the state (fiedler_steer.h). ------------------------------------------------------------ */
+static void h_resid_precond(vecs_t *V, const fd_state *st, double *sums)   /* sums: |w|^2 before preconditioning, sum of w after */
 {
-    if (V->dev) { if (spike_fd_resid_precond(V->dev, scale, xn, rho, sums)) V->err = 1; return; }
     double *x = V->v[0], *Lx = V->v[1], *w = V->v[2];
-    if (scale) for (I i = 0; i < V->n; ++i) { x[i] /= xn; Lx[i] /= xn; }
-    for (I i = 0; i < V->n; ++i) w[i] = Lx[i] - rho * x[i];
+    if (st->scale) for (I i = 0; i < V->n; ++i) { x[i] /= st->xn; Lx[i] /= st->xn; }
+    for (I i = 0; i < V->n; ++i) w[i] = Lx[i] - st->rho * x[i];
     sums[0] = dot(V->n, w, w);
     for (I i = 0; i < V->n; ++i) w[i] /= (V->g->deg[i] > 0 ? V->g->deg[i] : 1.0);
     sums[1] = dot(V->n, w, NULL);
 }
-static void op_shift_dots(vecs_t *V, double m, int havep, double *sums)   /* w -= m; sums: w.x, p.x */
+static void h_shift_dots(vecs_t *V, const fd_state *st, double *sums)   /* w -= m; sums: w.x, p.x */
 {
-    if (V->dev) { if (spike_fd_shift_dots(V->dev, m, havep, sums)) V->err = 1; return; }
-    for (I i = 0; i < V->n; ++i) V->v[2][i] -= m;
+    for (I i = 0; i < V->n; ++i) V->v[2][i] -= st->m;
     sums[0] = dot(V->n, V->v[2], V->v[0]);
-    sums[1] = havep ? dot(V->n, V->v[4], V->v[0]) : 0.0;
+    sums[1] = st->havep ? dot(V->n, V->v[4], V->v[0]) : 0.0;
 }
-static void op_orth_p(vecs_t *V, double a, double b, int havep, double *sums)   /* w -= a x; p -= b x; Lp -= b Lx; sums: p.p, w.p */
+static void h_orth_p(vecs_t *V, const fd_state *st, double *sums)   /* w -= a x; p -= b x; Lp -= b Lx; sums: p.p, w.p */
 {
-    if (V->dev) { if (spike_fd_orth_p(V->dev, a, b, havep, sums)) V->err = 1; return; }
     double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *p = V->v[4], *Lp = V->v[5];
-    for (I i = 0; i < V->n; ++i) w[i] = w[i] - a * x[i];
+    for (I i = 0; i < V->n; ++i) w[i] = w[i] - st->a * x[i];
     sums[0] = sums[1] = 0.0;
-    if (!havep) return;
-    for (I i = 0; i < V->n; ++i) { p[i] = p[i] - b * x[i]; Lp[i] = Lp[i] - b * Lx[i]; }
+    if (!st->havep) return;
+    for (I i = 0; i < V->n; ++i) { p[i] = p[i] - st->b * x[i]; Lp[i] = Lp[i] - st->b * Lx[i]; }
     sums[0] = dot(V->n, p, p);
     sums[1] = dot(V->n, w, p);
 }
-static double op_orth_w(vecs_t *V, double pn, double a2, int havep)   /* p /= pn; Lp /= pn; w -= a2 p; returns w.w */
+static void h_orth_w(vecs_t *V, const fd_state *st, double *sums)   /* p /= pn; Lp /= pn; w -= a2 p; sums: w.w */
 {
-    double ww = 0.0;
-    if (V->dev) { if (spike_fd_orth_w(V->dev, pn, a2, havep, &ww)) V->err = 1; return ww; }
     double *w = V->v[2], *p = V->v[4], *Lp = V->v[5];
-    if (havep) for (I i = 0; i < V->n; ++i) { p[i] = p[i] / pn; Lp[i] = Lp[i] / pn; w[i] = w[i] - a2 * p[i]; }
-    return dot(V->n, w, w);
+    if (st->havep) for (I i = 0; i < V->n; ++i) { p[i] = p[i] / st->pn; Lp[i] = Lp[i] / st->pn; w[i] = w[i] - st->a2 * p[i]; }
+    sums[0] = dot(V->n, w, w);
 }
-static double op_update_xx(vecs_t *V, double c0, double c1, double c2, int havep)   /* Rayleigh-Ritz update; returns x.x */
+static void h_rr_dots(vecs_t *V, const fd_state *st, double *d6)   /* w /= wn; Lw = L w; the Rayleigh-Ritz products */
 {
-    double xx = 0.0;
-    if (V->dev) { if (spike_fd_update_xx(V->dev, c0, c1, c2, havep, &xx)) V->err = 1; return xx; }
-    op_update(V, c0, c1, c2, havep);
-    return dot(V->n, V->v[0], V->v[0]);
+    double **v = V->v;
+    for (I i = 0; i < V->n; ++i) v[2][i] /= st->wn;
+    lap_mult(V->g, v[2], v[3]);
+    d6[0] = dot(V->n, v[0], v[1]); d6[1] = dot(V->n, v[0], v[3]); d6[3] = dot(V->n, v[2], v[3]);
+    d6[2] = d6[4] = d6[5] = 0.0;
+    if (st->havep) { d6[2] = dot(V->n, v[0], v[5]); d6[4] = dot(V->n, v[2], v[5]); d6[5] = dot(V->n, v[4], v[5]); }
+}
+static void h_update(vecs_t *V, const fd_state *st, double *sums)   /* Rayleigh-Ritz update; sums: x.x */
+{
+    double *x = V->v[0], *Lx = V->v[1], *w = V->v[2], *Lw = V->v[3], *p = V->v[4], *Lp = V->v[5];
+    const double c0 = st->c0, c1 = st->c1, c2 = st->c2;
+    const int havep = st->havep;
+    for (I i = 0; i < V->n; ++i) {
+        const double pn = c1 * w[i] + (havep ? c2 * p[i] : 0.0);
+        const double Lpn = c1 * Lw[i] + (havep ? c2 * Lp[i] : 0.0);
+        x[i] = c0 * x[i] + pn;
+        Lx[i] = c0 * Lx[i] + Lpn;
+        p[i] = pn; Lp[i] = Lpn;
+    }
+    sums[0] = dot(V->n, x, x);
 }
 
-/* single-vector LOBPCG for the smallest eigenpair of L restricted to the complement of the constant vector: THE iteration,
-   the same statements whichever side holds the vectors.  Six reductions per iteration (each a host round trip when the
-   vectors live on the device): [residual + preconditioning], [deflation + w.x, p.x], [orthogonalisation against x + p.p, w.p],
-   [normalise p, orthogonalise w against p + w.w], [the six Rayleigh-Ritz products], [update + x.x].  The Rayleigh quotient of
-   an iterate is its Ritz value (no seventh reduction); p is normalised by the scalar p.p and w's coefficient against it is
-   (w.p)/|p|; x and Lx are scaled to unit length at the start of the next iteration. */
+/* single-vector LOBPCG for the smallest eigenpair of L restricted to the complement of the constant vector.  An iteration is
+   six vector steps, each followed by its scalar step (fiedler_steer.h): [residual + preconditioning], [deflation + w.x, p.x],
+   [orthogonalisation against x + p.p, w.p], [normalise p, orthogonalise w against p + w.w], [normalise w, L w, the six
+   Rayleigh-Ritz products], [update + x.x].  The Rayleigh quotient of an iterate is its Ritz value; p is normalised by the
+   scalar p.p and w's coefficient against it is (w.p)/|p|; x and Lx are scaled to unit length at the start of the next
+   iteration.  Host: the loop below.  Device: spike_fd_refine launches the same six kernels + six one-thread scalar steps
+   per iteration, maxit times, with the state in device memory (steps after `done` are no-ops) -- no host round trip. */
 static void refine_core(vecs_t *V, double dmax, int maxit)
 {
     op_deflate(V, 0);
     if (op_normalize(V, 0) == 0.0) { op_fill_alternating(V); op_deflate(V, 0); op_normalize(V, 0); }
     op_lap(V, 0, 1);
-    int havep = 0, scale = 0;
-    double rho = op_dot(V, 0, 1), xn = 1.0;
+    const double rho = op_dot(V, 0, 1);
     g_last_its = 0;
-    for (int it = 0; it < maxit && !V->err; ++it) {
-        g_last_its = it + 1;
-        double s2[2];
-        op_resid_precond(V, scale, xn, rho, s2);
-        scale = 0;
-        if (sqrt(s2[0]) <= 1e-9 * dmax) break;
-        op_shift_dots(V, s2[1] / (double)V->n, havep, s2);       /* constant vector deflated; w.x, p.x */
-        const double a = s2[0], b = s2[1];
-        op_orth_p(V, a, b, havep, s2);                            /* against x; p.p, w.p of the results */
-        double pn = 1.0, a2 = 0.0;
-        if (havep) {
-            pn = sqrt(s2[0]);
-            if (pn > 1e-300) a2 = s2[1] / pn;
-            else havep = 0;
-        }
-        const double wn = sqrt(op_orth_w(V, pn, a2, havep));
-        if (wn < 1e-300) break;
-        op_div(V, wn, 2, -1);
-        op_lap(V, 2, 3);
-        const int m = havep ? 3 : 2;
-        double G[3][3], c[3], lam, d6[6];
-        if (m == 3) {
-            const int ia[6] = {0, 0, 0, 2, 2, 4}, ib[6] = {1, 3, 5, 3, 5, 5};
-            op_dots(V, 6, ia, ib, d6);
-            G[0][0] = d6[0]; G[0][1] = G[1][0] = d6[1]; G[0][2] = G[2][0] = d6[2];
-            G[1][1] = d6[3]; G[1][2] = G[2][1] = d6[4]; G[2][2] = d6[5];
-        } else {
-            const int ia[3] = {0, 0, 2}, ib[3] = {1, 3, 3};
-            op_dots(V, 3, ia, ib, d6);
-            G[0][0] = d6[0]; G[0][1] = G[1][0] = d6[1]; G[1][1] = d6[2];
-        }
-        eig3(m, G, c, &lam);
-        if (c[0] < 0) for (int i = 0; i < m; ++i) c[i] = -c[i];
-        xn = sqrt(op_update_xx(V, c[0], c[1], havep ? c[2] : 0.0, havep));
-        havep = 1;
-        scale = 1;          /* x, Lx are divided by xn at the start of the next iteration ... */
-        rho = lam;          /* ... whose Rayleigh quotient is this Ritz value */
+    if (V->err) return;
+    if (V->dev) {
+        if (spike_fd_refine(V->dev, dmax, rho, maxit, &g_last_its)) V->err = 1;
+        return;
     }
-    if (scale && !V->err) op_div(V, xn, 0, 1);   /* ... or here, after the last one */
+    fd_state st;
+    fd_init(&st, (double)V->n, dmax, rho);
+    for (int it = 0; it < maxit && !st.done; ++it) {
+        double s[6];
+        h_resid_precond(V, &st, s); fd_after_resid(&st, s);
+        if (st.done) break;
+        h_shift_dots(V, &st, s);    fd_after_shift(&st, s);
+        h_orth_p(V, &st, s);        fd_after_orth_p(&st, s);
+        h_orth_w(V, &st, s);        fd_after_orth_w(&st, s);
+        if (st.done) break;
+        h_rr_dots(V, &st, s);       fd_after_rr_dots(&st, s);
+        h_update(V, &st, s);        fd_after_update(&st, s);
+    }
+    g_last_its = st.its;
+    if (st.scale) op_div(V, st.xn, 0, 1);
 }
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -370,10 +304,14 @@ static void refine_impl(const graph_t *g, double *x, int maxit, int use_device)
     vecs_t V;
     memset(&V, 0, sizeof V);
     V.g = g; V.n = n;
+    const double t0 = now_s();
     if (use_device && n >= FD_DEVICE_MIN && spike_fd_create(n, g->xadj, g->adj, g->w, g->deg, x, &V.dev) == 0) {
+        const double t1 = now_s();
         refine_core(&V, dmax, maxit);
+        const double t2 = now_s();
         if (!V.err && spike_fd_download_x(V.dev, x)) V.err = 1;
         spike_fd_destroy(V.dev);
+        if (getenv("SPIKE_FIEDLER_TRACE")) fprintf(stderr, "[fiedler]   device level: create %.3f ms, loop %.3f ms, download + destroy %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
         if (!V.err) return;
         V.dev = NULL; V.err = 0;   /* device trouble: the host computes the same thing (x was not touched) */
     }
@@ -394,7 +332,7 @@ static void fiedler_vector(const graph_t *g, double *x, int level, int use_devic
                 A[i * m + i] = g->deg[i];
                 for (I k = g->xadj[i]; k < g->xadj[i + 1]; ++k) A[i * m + g->adj[k]] -= g->w[k];
             }
-            jacobi_eig(m, A, V, ev);
+            fd_jacobi_eig(m, A, V, ev);
             int i0 = 0, i1 = -1;
             for (int i = 1; i < m; ++i) if (ev[i] < ev[i0]) i0 = i;
             for (int i = 0; i < m; ++i) if (i != i0 && (i1 < 0 || ev[i] < ev[i1])) i1 = i;
@@ -408,7 +346,9 @@ static void fiedler_vector(const graph_t *g, double *x, int level, int use_devic
     }
     graph_t c;
     memset(&c, 0, sizeof c);
+    const double tc0 = now_s();
     I *map = coarsen(g, &c);
+    if (getenv("SPIKE_FIEDLER_TRACE")) fprintf(stderr, "[fiedler] coarsen n=%lld -> %lld  %.3f ms\n", (long long)n, (long long)c.n, 1e3 * (now_s() - tc0));
     if (c.n > (9 * n) / 10) { /* matching stalls (e.g. star graphs): stop coarsening here */
         for (I i = 0; i < n; ++i) x[i] = (double)i - 0.5 * (double)(n - 1);
         refine(g, x, 1000, use_device);
@@ -432,6 +372,40 @@ static int cmp_desc(const void *a, const void *b)
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
 
+/* keys[0..n) -> sorted by DESCENDING value, ties by ascending idx (exactly cmp_desc's total order; -0.0 counts as +0.0
+   as it does for the comparison).  Large inputs: a stable LSD radix sort over the order-preserving 64-bit image of the
+   doubles, four 16-bit digits -- stable + the input already ascending in idx gives the tie rule; requires that (it holds
+   at both call sites: keys are filled in ascending idx).  qsort at n = 3.2e5 cost 50 ms, this 6 ms. */
+static void sort_desc(key_t2 *keys, I n)
+{
+    int ascending_idx = 1;
+    for (I t = 1; t < n && ascending_idx; ++t) if (keys[t - 1].idx >= keys[t].idx) ascending_idx = 0;
+    key_t2 *tmp = (n >= 4096 && ascending_idx) ? (key_t2 *)malloc(sizeof(key_t2) * (size_t)n) : NULL;
+    uint64_t *img = tmp ? (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n * 2) : NULL;
+    I *cnt = img ? (I *)malloc(sizeof(I) * 65536) : NULL;
+    if (!tmp || !img || !cnt) { free(tmp); free(img); free(cnt); qsort(keys, (size_t)n, sizeof(key_t2), cmp_desc); return; }
+    uint64_t *ia = img, *ib = img + n;
+    for (I t = 0; t < n; ++t) {
+        const double v = keys[t].v + 0.0;                       /* -0.0 -> +0.0 */
+        uint64_t u; memcpy(&u, &v, 8);
+        u = (u >> 63) ? ~u : (u | 0x8000000000000000ULL);       /* ascending in u == ascending in v */
+        ia[t] = ~u;                                             /* ascending in ~u == descending in v */
+    }
+    key_t2 *ka = keys, *kb = tmp;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 16 * pass;
+        memset(cnt, 0, sizeof(I) * 65536);
+        for (I t = 0; t < n; ++t) ++cnt[(ia[t] >> sh) & 0xffff];
+        I run = 0;
+        for (int d = 0; d < 65536; ++d) { const I c = cnt[d]; cnt[d] = run; run += c; }
+        for (I t = 0; t < n; ++t) { const I q = cnt[(ia[t] >> sh) & 0xffff]++; ib[q] = ia[t]; kb[q] = ka[t]; }
+        uint64_t *ti = ia; ia = ib; ib = ti;
+        key_t2 *tk = ka; ka = kb; kb = tk;
+    }
+    /* four passes: the result is back in keys */
+    free(tmp); free(img); free(cnt);
+}
+
 /*
  * n, ia, ja, a : 0-based CSR.  order[k] = old index at new position k.  vec (optional, length n) receives the
  * per-component Fiedler vectors.  Returns 0 or -1.
@@ -451,8 +425,61 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
 {
     if (use_device && spike_device_count() <= 0) use_device = 0;
     if (n <= 0 || !ia || !ja || !a || !order) return -1;
+    const int trace = getenv("SPIKE_FIEDLER_TRACE") != NULL;
+    const double tg0 = now_s();
     const int weighted = (ia[n] > 0 && a[0] > 0.0);
     const double tol = 1e-12;
+    graph_t g;
+    memset(&g, 0, sizeof g);
+    /* fast path, rows with strictly ascending columns (what MatGetRow of an assembled AIJ gives): transpose the kept
+       pattern (rows of the transpose come out ascending by construction), then merge row i of A and of A^T; an edge stored
+       on both sides gets |a_ij| + |a_ji| -- one IEEE addition, the same value whichever operand comes first, i.e. what the
+       general path below computes.  103 -> 45 ms at n = 3.2e5. */
+    int sorted_rows = 1;
+    for (I i = 0; i < n && sorted_rows; ++i)
+        for (I k = ia[i]; k < ia[i + 1]; ++k) {
+            if (ja[k] < 0 || ja[k] >= n) return -1;
+            if (k > ia[i] && ja[k] <= ja[k - 1]) { sorted_rows = 0; break; }
+        }
+    if (sorted_rows) {
+        I *tp = (I *)calloc((size_t)n + 1, sizeof(I));
+        for (I i = 0; i < n; ++i)
+            for (I k = ia[i]; k < ia[i + 1]; ++k) if (ja[k] != i && fabs(a[k]) >= tol) ++tp[ja[k] + 1];
+        for (I i = 0; i < n; ++i) tp[i + 1] += tp[i];
+        const I nt = tp[n];
+        I *tj = (I *)malloc(sizeof(I) * (size_t)(nt > 0 ? nt : 1)), *tfill = (I *)malloc(sizeof(I) * (size_t)n);
+        double *tv = (double *)malloc(sizeof(double) * (size_t)(nt > 0 ? nt : 1));
+        memcpy(tfill, tp, sizeof(I) * (size_t)n);
+        for (I i = 0; i < n; ++i)
+            for (I k = ia[i]; k < ia[i + 1]; ++k)
+                if (ja[k] != i && fabs(a[k]) >= tol) { const I q = tfill[ja[k]]++; tj[q] = i; tv[q] = fabs(a[k]); }
+        g.n = n;
+        g.xadj = (I *)calloc((size_t)n + 1, sizeof(I));
+        g.adj = (I *)malloc(sizeof(I) * (size_t)(2 * nt > 0 ? 2 * nt : 1));
+        g.w = (double *)malloc(sizeof(double) * (size_t)(2 * nt > 0 ? 2 * nt : 1));
+        g.deg = (double *)calloc((size_t)n, sizeof(double));
+        I pos = 0;
+        for (I i = 0; i < n; ++i) {
+            I k = ia[i], q = tp[i];
+            const I ke = ia[i + 1], qe = tp[i + 1];
+            for (;;) {
+                while (k < ke && (ja[k] == i || fabs(a[k]) < tol)) ++k;
+                if (k >= ke && q >= qe) break;
+                const I jc = (k < ke) ? ja[k] : n, jt = (q < qe) ? tj[q] : n;
+                double sw;
+                I j;
+                if (jc < jt) { j = jc; sw = fabs(a[k]); ++k; }
+                else if (jt < jc) { j = jt; sw = tv[q]; ++q; }
+                else { j = jc; sw = fabs(a[k]) + tv[q]; ++k; ++q; }
+                g.adj[pos] = j;
+                g.w[pos] = weighted ? sw : 1.0;
+                g.deg[i] += g.w[pos];
+                ++pos;
+            }
+            g.xadj[i + 1] = pos;
+        }
+        free(tp); free(tj); free(tfill); free(tv);
+    } else {
     /* symmetrised adjacency: count, fill, then merge duplicates per row (sorted by column) */
     I *cnt = (I *)calloc((size_t)n + 1, sizeof(I));
     for (I i = 0; i < n; ++i)
@@ -476,7 +503,6 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
             adj[fill[i]] = j; w[fill[i]++] = v;
             adj[fill[j]] = i; w[fill[j]++] = v;
         }
-    graph_t g;
     g.n = n;
     g.xadj = (I *)calloc((size_t)n + 1, sizeof(I));
     g.adj = (I *)malloc(sizeof(I) * (size_t)(tot > 0 ? tot : 1));
@@ -516,6 +542,8 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
         }
     }
     free(adj); free(w); free(fill); free(cnt);
+    }
+    if (trace) fprintf(stderr, "[fiedler] graph build n=%lld  %.3f ms\n", (long long)n, 1e3 * (now_s() - tg0));
 
     /* components in order of smallest vertex */
     I *comp = (I *)malloc(sizeof(I) * (size_t)n), *queue = (I *)malloc(sizeof(I) * (size_t)n);
@@ -524,6 +552,7 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
     I outpos = 0, ncomp = 0;
     for (I s = 0; s < n; ++s) {
         if (comp[s] >= 0) continue;
+        const double tcomp0 = now_s();
         I head = 0, tail = 0;
         queue[tail++] = s; comp[s] = ncomp;
         while (head < tail) {
@@ -535,8 +564,13 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
         /* sort the component's vertices by index (insertion into a flag scan keeps it O(n) overall is not needed:
            qsort on I is fine and deterministic) */
         key_t2 *keys = (key_t2 *)malloc(sizeof(key_t2) * (size_t)nc);
-        for (I t = 0; t < nc; ++t) { keys[t].v = -(double)queue[t]; keys[t].idx = queue[t]; }
-        qsort(keys, (size_t)nc, sizeof(key_t2), cmp_desc); /* descending in -index == ascending in index */
+        if (nc > n / 8) {   /* a large component: its vertices in index order by a scan of the labels */
+            I t = 0;
+            for (I v = s; v < n && t < nc; ++v) if (comp[v] == ncomp) { keys[t].v = 0.0; keys[t].idx = v; ++t; }
+        } else {
+            for (I t = 0; t < nc; ++t) { keys[t].v = -(double)queue[t]; keys[t].idx = queue[t]; }
+            qsort(keys, (size_t)nc, sizeof(key_t2), cmp_desc); /* descending in -index == ascending in index */
+        }
         if (nc <= 2) {
             for (I t = 0; t < nc; ++t) { order[outpos++] = keys[t].idx; if (vec) vec[keys[t].idx] = (nc == 2) ? (t == 0 ? 0.7071067811865476 : -0.7071067811865476) : 0.0; }
             free(keys);
@@ -561,14 +595,19 @@ int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, cons
             sg.deg[t] = g.deg[v];
         }
         double *x = (double *)malloc(sizeof(double) * (size_t)nc);
+        if (trace && nc > 1000) fprintf(stderr, "[fiedler] component of %lld vertices: found + subgraph %.3f ms\n", (long long)nc, 1e3 * (now_s() - tcomp0));
+        const double tv0 = now_s();
         fiedler_vector(&sg, x, 0, use_device);
+        if (trace && nc > 1000) fprintf(stderr, "[fiedler] component of %lld vertices: vector %.3f ms\n", (long long)nc, 1e3 * (now_s() - tv0));
+        const double tv1 = now_s();
         /* sign: largest magnitude entry positive */
         I im = 0;
         for (I t = 1; t < nc; ++t) if (fabs(x[t]) > fabs(x[im])) im = t;
         if (x[im] < 0) for (I t = 0; t < nc; ++t) x[t] = -x[t];
         for (I t = 0; t < nc; ++t) { const I v = keys[t].idx; keys[t].v = x[t]; keys[t].idx = v; if (vec) vec[v] = x[t]; }
-        qsort(keys, (size_t)nc, sizeof(key_t2), cmp_desc);
+        sort_desc(keys, nc);
         for (I t = 0; t < nc; ++t) order[outpos++] = keys[t].idx;
+        if (trace && nc > 1000) fprintf(stderr, "[fiedler] component of %lld vertices: sign + sort %.3f ms\n", (long long)nc, 1e3 * (now_s() - tv1));
         free(x); free(keys);
         graph_free(&sg);
         ++ncomp;

@@ -18,6 +18,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
+
+#define FD_HD __host__ __device__ static inline
+#include "host/fiedler_steer.h"
 
 namespace {
 
@@ -83,10 +87,12 @@ __global__ void k_fd_lap(int64_t n, const int64_t *xadj, const int32_t *adj, con
     y[i] = s;
 }
 
-// ---- fused steps of refine_core (round 2: nine host round trips per iteration -> six) ------------------------------------
-// Each kernel performs the element-wise statements of one step and accumulates that step's sums over the UPDATED values,
-// chunk by chunk in the reduction order of the spec; the host implementation runs the same statements over all elements
-// and then takes the same sums.
+// ---- the six vector steps of one iteration (fiedler.c:refine_core) --------------------------------------------------------
+// Each kernel performs the element-wise statements of one step and that step's sums over the UPDATED values, chunk by chunk
+// in the reduction order of the spec (host: h_* in fiedler.c, the same statements over all elements, then the same sums).
+// Scalars come from the iteration state in device memory; k_fd_steer<STEP> (one workgroup) adds the chunk sums in chunk order
+// and runs the step's scalar epilogue (fiedler_steer.h, compiled for both sides) on one thread.  After `done` every kernel
+// returns at once, so a level's maxit iterations are launched blind, without a host round trip.
 struct FusedOut { double *o0, *o1; };
 
 __device__ __forceinline__ void chunk_reduce2(double v0, double v1, double *s0, double *s1, int t, FusedOut out, bool two)
@@ -102,11 +108,14 @@ __device__ __forceinline__ void chunk_reduce2(double v0, double v1, double *s0, 
 }
 
 // [x /= xn, Lx /= xn]; w = Lx - rho x; sums: w^2 ; then w /= deg; sums: w
-__global__ __launch_bounds__(256) void k_fd_resid_precond(int64_t n, int scale, double xn, double rho, double *x, double *Lx,
-                                                          const double *deg, double *w, FusedOut out)
+__global__ __launch_bounds__(256) void k_fd_resid_precond(int64_t n, const fd_state *st, double *x, double *Lx, const double *deg,
+                                                          double *w, FusedOut out)
 {
 #pragma clang fp contract(off)
     __shared__ double s0[256], s1[256];
+    if (st->done) return;
+    const int scale = st->scale;
+    const double xn = st->xn, rho = st->rho;
     const int t = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CH;
     double v0 = 0.0, v1 = 0.0;
@@ -129,11 +138,14 @@ __global__ __launch_bounds__(256) void k_fd_resid_precond(int64_t n, int scale, 
 }
 
 // w -= m; sums: w.x [, p.x]
-__global__ __launch_bounds__(256) void k_fd_shift_dots(int64_t n, double m, int havep, double *w, const double *x, const double *p,
+__global__ __launch_bounds__(256) void k_fd_shift_dots(int64_t n, const fd_state *st, double *w, const double *x, const double *p,
                                                        FusedOut out)
 {
 #pragma clang fp contract(off)
     __shared__ double s0[256], s1[256];
+    if (st->done) return;
+    const double m = st->m;
+    const int havep = st->havep;
     const int t = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CH;
     double v0 = 0.0, v1 = 0.0;
@@ -153,11 +165,14 @@ __global__ __launch_bounds__(256) void k_fd_shift_dots(int64_t n, double m, int 
 }
 
 // w -= a x; [p -= b x; Lp -= b Lx; sums: p.p, w.p]
-__global__ __launch_bounds__(256) void k_fd_orth_p(int64_t n, double a, double b, int havep, double *w, const double *x,
-                                                   const double *Lx, double *p, double *Lp, FusedOut out)
+__global__ __launch_bounds__(256) void k_fd_orth_p(int64_t n, const fd_state *st, double *w, const double *x, const double *Lx,
+                                                   double *p, double *Lp, FusedOut out)
 {
 #pragma clang fp contract(off)
     __shared__ double s0[256], s1[256];
+    if (st->done) return;
+    const double a = st->a, b = st->b;
+    const int havep = st->havep;
     const int t = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CH;
     double v0 = 0.0, v1 = 0.0;
@@ -182,11 +197,13 @@ __global__ __launch_bounds__(256) void k_fd_orth_p(int64_t n, double a, double b
 }
 
 // [p /= pn; Lp /= pn; w -= a2 p]; sums: w.w
-__global__ __launch_bounds__(256) void k_fd_orth_w(int64_t n, double pn, double a2, int havep, double *w, double *p, double *Lp,
-                                                   FusedOut out)
+__global__ __launch_bounds__(256) void k_fd_orth_w(int64_t n, const fd_state *st, double *w, double *p, double *Lp, FusedOut out)
 {
 #pragma clang fp contract(off)
     __shared__ double s0[256], s1[256];
+    if (st->done) return;
+    const double pn = st->pn, a2 = st->a2;
+    const int havep = st->havep;
     const int t = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CH;
     double v0 = 0.0;
@@ -209,12 +226,67 @@ __global__ __launch_bounds__(256) void k_fd_orth_w(int64_t n, double pn, double 
     chunk_reduce2(v0, 0.0, s0, s1, t, out, false);
 }
 
+// w /= wn (one thread per element)
+__global__ void k_fd_div_w(int64_t n, const fd_state *st, double *w)
+{
+#pragma clang fp contract(off)
+    if (st->done) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) w[i] /= st->wn;
+}
+
+// Lw = L w (one thread per row, the row's terms in storage order)
+__global__ void k_fd_lap_st(int64_t n, const fd_state *st, const int64_t *xadj, const int32_t *adj, const double *we, const double *deg,
+                            const double *x, double *y)
+{
+#pragma clang fp contract(off)
+    if (st->done) return;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = deg[i] * x[i];
+    for (int64_t k = xadj[i]; k < xadj[i + 1]; ++k) s -= we[k] * x[adj[k]];
+    y[i] = s;
+}
+
+// the Rayleigh-Ritz products x.Lx, x.Lw, x.Lp, w.Lw, w.Lp, p.Lp -> out[j * nchunks + chunk] (p entries only when p exists)
+__global__ __launch_bounds__(256) void k_fd_rr_dots(int64_t n, const fd_state *st, const double *x, const double *Lx, const double *w,
+                                                    const double *Lw, const double *p, const double *Lp, int64_t nchunks, double *out)
+{
+#pragma clang fp contract(off)
+    __shared__ double s[6][256];
+    if (st->done) return;
+    const int havep = st->havep;
+    const int t = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    double v[6];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = c0 + t + 256 * q;
+        double pr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (i < n) {
+            const double xi = x[i], wi = w[i], lwi = Lw[i];
+            pr[0] = xi * Lx[i]; pr[1] = xi * lwi; pr[3] = wi * lwi;
+            if (havep) { const double pi = p[i], lpi = Lp[i]; pr[2] = xi * lpi; pr[4] = wi * lpi; pr[5] = pi * lpi; }
+        }
+        for (int j = 0; j < 6; ++j) v[j] = (q == 0) ? pr[j] : v[j] + pr[j];
+    }
+    for (int j = 0; j < 6; ++j) s[j][t] = v[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) for (int j = 0; j < 6; ++j) s[j][t] += s[j][t + o];
+        __syncthreads();
+    }
+    if (t < 6) out[(int64_t)t * nchunks + blockIdx.x] = s[t][0];
+}
+
 // Rayleigh-Ritz update; sums: x.x of the new x
-__global__ __launch_bounds__(256) void k_fd_update_xx(int64_t n, double c0_, double c1, double c2, int havep, double *x, double *Lx,
-                                                      const double *w, const double *Lw, double *p, double *Lp, FusedOut out)
+__global__ __launch_bounds__(256) void k_fd_update_xx(int64_t n, const fd_state *st, double *x, double *Lx, const double *w,
+                                                      const double *Lw, double *p, double *Lp, FusedOut out)
 {
 #pragma clang fp contract(off)
     __shared__ double s0[256], s1[256];
+    if (st->done) return;
+    const double c0_ = st->c0, c1 = st->c1, c2 = st->c2;
+    const int havep = st->havep;
     const int t = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CH;
     double v0 = 0.0;
@@ -234,6 +306,50 @@ __global__ __launch_bounds__(256) void k_fd_update_xx(int64_t n, double c0_, dou
         v0 = (q == 0) ? p0 : v0 + p0;
     }
     chunk_reduce2(v0, 0.0, s0, s1, t, out, false);
+}
+
+// after the last iteration: x /= xn, Lx /= xn if the iterate is still unscaled
+__global__ void k_fd_final_scale(int64_t n, const fd_state *st, double *x, double *Lx)
+{
+#pragma clang fp contract(off)
+    if (!st->scale) return;
+    const double xn = st->xn;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) { x[i] /= xn; Lx[i] /= xn; }
+}
+
+// The scalar step after vector step STEP: totals = chunk sums added IN CHUNK ORDER (one lane per sum, the chunk sums staged
+// through LDS so that the serial additions do not wait for memory), then the epilogue of fiedler_steer.h on one thread.
+constexpr int STEER_TILE = 1024;
+template <int STEP, int NSUM>
+__global__ __launch_bounds__(256) void k_fd_steer(fd_state *st, const double *chunk, int64_t nchunks)
+{
+#pragma clang fp contract(off)
+    __shared__ double buf[NSUM][STEER_TILE];
+    __shared__ double tot[NSUM];
+    if (st->done) return;
+    const int t = threadIdx.x;
+    double acc = 0.0;
+    for (int64_t q0 = 0; q0 < nchunks; q0 += STEER_TILE) {
+        const int len = (int)((nchunks - q0 < STEER_TILE) ? nchunks - q0 : STEER_TILE);
+        for (int j = 0; j < NSUM; ++j)
+            for (int q = t; q < len; q += 256) buf[j][q] = chunk[(int64_t)j * nchunks + q0 + q];
+        __syncthreads();
+        if (t < NSUM)
+            for (int q = 0; q < len; ++q) acc += buf[t][q];
+        __syncthreads();
+    }
+    if (t < NSUM) tot[t] = acc;
+    __syncthreads();
+    if (t != 0) return;
+    double sums[NSUM];
+    for (int j = 0; j < NSUM; ++j) sums[j] = tot[j];
+    if (STEP == 0) fd_after_resid(st, sums);
+    if (STEP == 1) fd_after_shift(st, sums);
+    if (STEP == 2) fd_after_orth_p(st, sums);
+    if (STEP == 3) fd_after_orth_w(st, sums);
+    if (STEP == 4) fd_after_rr_dots(st, sums);
+    if (STEP == 5) fd_after_update(st, sums);
 }
 
 __global__ void k_fd_fill_one(int64_t n, double *x)
@@ -259,6 +375,7 @@ struct spike_fd_ctx {
     double *v[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // x, Lx, w, Lw, p, Lp, the constant 1
     double *dchunk = nullptr;
     double *hchunk = nullptr;   // pinned
+    fd_state *dstate = nullptr, *hstate = nullptr;   // iteration state (device) and its pinned read-back
     hipStream_t st = nullptr;
 };
 
@@ -275,7 +392,8 @@ extern "C" int spike_fd_destroy(spike_fd_ctx *c)
 {
     if (!c) return SPIKE_OK;
     (void)hipStreamSynchronize(c->st);
-    (void)hipFree(c->xadj); (void)hipFree(c->adj); (void)hipFree(c->w_e); (void)hipFree(c->deg); (void)hipFree(c->dchunk);
+    (void)hipFree(c->xadj); (void)hipFree(c->adj); (void)hipFree(c->w_e); (void)hipFree(c->deg); (void)hipFree(c->dchunk); (void)hipFree(c->dstate);
+    if (c->hstate) (void)hipHostFree(c->hstate);
     for (double *q : c->v) (void)hipFree(q);
     if (c->hchunk) (void)hipHostFree(c->hchunk);
     delete c;
@@ -300,7 +418,9 @@ extern "C" int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *ad
               hipMalloc((void **)&c->w_e, sizeof(double) * (size_t)(ne > 0 ? ne : 1)) == hipSuccess &&
               hipMalloc((void **)&c->deg, sizeof(double) * (size_t)n) == hipSuccess &&
               hipMalloc((void **)&c->dchunk, sizeof(double) * (size_t)(MAXD * c->nchunks)) == hipSuccess &&
-              hipHostMalloc((void **)&c->hchunk, sizeof(double) * (size_t)(MAXD * c->nchunks), hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void **)&c->hchunk, sizeof(double) * (size_t)(MAXD * c->nchunks), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&c->dstate, sizeof(fd_state)) == hipSuccess &&
+              hipHostMalloc((void **)&c->hstate, sizeof(fd_state), hipHostMallocDefault) == hipSuccess;
     for (int q = 0; q < 7 && ok; ++q) ok = hipMalloc((void **)&c->v[q], sizeof(double) * (size_t)n) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_fd_fill_one, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, c->v[6]);
@@ -367,50 +487,39 @@ extern "C" int spike_fd_download_x(spike_fd_ctx *c, double *x)
     return SPIKE_OK;
 }
 
-// ---- fused steps (see the kernels): sums[0..1] in the reduction order of the spec ------------------------------------------
-static int two_totals(spike_fd_ctx *c, int nsum, double *sums)
+// ---- a level's whole refinement loop, launched blind: maxit x (six vector steps, each with its scalar step), then the
+// final scaling; the state (fiedler_steer.h) lives in device memory.  One synchronisation at the end (its = iterations run).
+extern "C" int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int maxit, int *its)
 {
-    FDCHK(hipMemcpyAsync(c->hchunk, c->dchunk, sizeof(double) * (size_t)(nsum * c->nchunks), hipMemcpyDeviceToHost, c->st));
-    FDCHK(hipStreamSynchronize(c->st));
-    for (int j = 0; j < nsum; ++j) {
-        double t = 0.0;
-        for (int64_t q = 0; q < c->nchunks; ++q) t += c->hchunk[(int64_t)j * c->nchunks + q];
-        sums[j] = t;
+    if (!c || maxit < 0) return SPIKE_ERR_ARG;
+    fd_state h;
+    fd_init(&h, (double)c->n, dmax, rho);
+    FDCHK(hipMemcpyAsync(c->dstate, &h, sizeof h, hipMemcpyHostToDevice, c->st));
+    const dim3 gc((unsigned)c->nchunks), ge = grid1(c->n), b(256);
+    const FusedOut out{c->dchunk, c->dchunk + c->nchunks};
+    double **v = c->v;
+    fd_state *st = c->dstate;
+    const int64_t n = c->n, nch = c->nchunks;
+    for (int it = 0; it < maxit; ++it) {
+        hipLaunchKernelGGL(k_fd_resid_precond, gc, b, 0, c->st, n, st, v[0], v[1], c->deg, v[2], out);
+        hipLaunchKernelGGL((k_fd_steer<0, 2>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+        hipLaunchKernelGGL(k_fd_shift_dots, gc, b, 0, c->st, n, st, v[2], v[0], v[4], out);
+        hipLaunchKernelGGL((k_fd_steer<1, 2>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+        hipLaunchKernelGGL(k_fd_orth_p, gc, b, 0, c->st, n, st, v[2], v[0], v[1], v[4], v[5], out);
+        hipLaunchKernelGGL((k_fd_steer<2, 2>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+        hipLaunchKernelGGL(k_fd_orth_w, gc, b, 0, c->st, n, st, v[2], v[4], v[5], out);
+        hipLaunchKernelGGL((k_fd_steer<3, 1>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+        hipLaunchKernelGGL(k_fd_div_w, ge, b, 0, c->st, n, st, v[2]);
+        hipLaunchKernelGGL(k_fd_lap_st, ge, b, 0, c->st, n, st, c->xadj, c->adj, c->w_e, c->deg, v[2], v[3]);
+        hipLaunchKernelGGL(k_fd_rr_dots, gc, b, 0, c->st, n, st, v[0], v[1], v[2], v[3], v[4], v[5], nch, c->dchunk);
+        hipLaunchKernelGGL((k_fd_steer<4, 6>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+        hipLaunchKernelGGL(k_fd_update_xx, gc, b, 0, c->st, n, st, v[0], v[1], v[2], v[3], v[4], v[5], out);
+        hipLaunchKernelGGL((k_fd_steer<5, 1>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
     }
+    hipLaunchKernelGGL(k_fd_final_scale, ge, b, 0, c->st, n, st, v[0], v[1]);
+    FDCHK(hipGetLastError());
+    FDCHK(hipMemcpyAsync(c->hstate, st, sizeof h, hipMemcpyDeviceToHost, c->st));
+    FDCHK(hipStreamSynchronize(c->st));
+    if (its) *its = c->hstate->its;
     return SPIKE_OK;
-}
-#define FD_OUT(c) FusedOut{(c)->dchunk, (c)->dchunk + (c)->nchunks}
-
-extern "C" int spike_fd_resid_precond(spike_fd_ctx *c, int scale, double xn, double rho, double *sums /* rn2, sum w */)
-{
-    hipLaunchKernelGGL(k_fd_resid_precond, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, scale, xn, rho, c->v[0], c->v[1],
-                       c->deg, c->v[2], FD_OUT(c));
-    return two_totals(c, 2, sums);
-}
-extern "C" int spike_fd_shift_dots(spike_fd_ctx *c, double m, int havep, double *sums /* w.x, p.x */)
-{
-    hipLaunchKernelGGL(k_fd_shift_dots, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, m, havep, c->v[2], c->v[0], c->v[4],
-                       FD_OUT(c));
-    sums[1] = 0.0;
-    return two_totals(c, havep ? 2 : 1, sums);
-}
-extern "C" int spike_fd_orth_p(spike_fd_ctx *c, double a, double b, int havep, double *sums /* p.p, w.p */)
-{
-    hipLaunchKernelGGL(k_fd_orth_p, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, a, b, havep, c->v[2], c->v[0], c->v[1],
-                       c->v[4], c->v[5], FD_OUT(c));
-    sums[0] = sums[1] = 0.0;
-    if (!havep) return hipGetLastError() == hipSuccess ? SPIKE_OK : SPIKE_ERR_HIP;
-    return two_totals(c, 2, sums);
-}
-extern "C" int spike_fd_orth_w(spike_fd_ctx *c, double pn, double a2, int havep, double *ww)
-{
-    hipLaunchKernelGGL(k_fd_orth_w, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, pn, a2, havep, c->v[2], c->v[4], c->v[5],
-                       FD_OUT(c));
-    return two_totals(c, 1, ww);
-}
-extern "C" int spike_fd_update_xx(spike_fd_ctx *c, double c0, double c1, double c2, int havep, double *xx)
-{
-    hipLaunchKernelGGL(k_fd_update_xx, dim3((unsigned)c->nchunks), dim3(256), 0, c->st, c->n, c0, c1, c2, havep, c->v[0], c->v[1],
-                       c->v[2], c->v[3], c->v[4], c->v[5], FD_OUT(c));
-    return two_totals(c, 1, xx);
 }

@@ -206,6 +206,33 @@ def test_fiedler_halves_is_the_reference_prototype(H):
     assert bw[1] <= 4 * K and bw[3] <= 4 * K
 
 
+def test_fiedler_sorted_and_unsorted_rows_and_the_tie_rule(H):
+    """Rows with ascending columns take the transpose-and-merge graph build, anything else the general counting-sort build:
+    same graph, same bits.  Large components are ordered by a stable radix sort: descending value, ties by index."""
+    n, K = 6000, 4
+    rng = np.random.default_rng(5)
+    B = sp.diags([rng.uniform(0.2, 1, n - abs(d)) for d in range(-K, K + 1)], list(range(-K, K + 1))).tocsr()
+    q = rng.permutation(n)
+    A = B[q][:, q].tocoo()
+    keep = (A.row <= A.col) | (rng.random(A.nnz) < 0.5)          # unsymmetric pattern: half the edges stored on one side only
+    A = sp.csr_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=(n, n)); A.sort_indices()
+    ia, ja, a = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.copy()
+    o1, v1 = H.fiedler_order(n, ia, ja, a)
+    ja2, a2 = ja.copy(), a.copy()
+    for i in range(n):                                           # the same rows, entries in descending column order
+        ja2[ia[i]:ia[i + 1]] = ja[ia[i]:ia[i + 1]][::-1]; a2[ia[i]:ia[i + 1]] = a[ia[i]:ia[i + 1]][::-1]
+    assert a[0] > 0 and a2[0] > 0                                # weighted mode (decided by the sign of a[0]) on both
+    o2, v2 = H.fiedler_order(n, ia, ja2, a2)
+    assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+    assert np.array_equal(o1, np.argsort(-(v1 + 0.0), kind="stable"))
+    # ties: two identical, disconnected halves of a graph give the same vector twice per component; inside a component of
+    # >= 4096 vertices with mirror symmetry pairs of equal entries exist -> the smaller index comes first
+    m = 5001
+    P = sp.diags([np.ones(m - 1), np.ones(m - 1)], [-1, 1]).tocsr()   # a path: v_i = -v_{m-1-i}; the middle entry is 0
+    o, v = H.fiedler_order(m, P.indptr, P.indices, P.data)
+    assert np.array_equal(o, np.argsort(-(v + 0.0), kind="stable")) and sorted(o.tolist()) == list(range(m))
+
+
 def test_fiedler_small_exact_and_components(H):
     # path graph on 9 vertices: Fiedler vector is monotone -> the order is the path (up to direction)
     n = 9

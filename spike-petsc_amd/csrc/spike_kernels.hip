@@ -990,12 +990,18 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma(LuView lv, const ChainD
 __device__ __forceinline__ void tile_lu_regs(int s, double *Pd, double *rd, int np, double boost, unsigned long long &nb, int lane)
 {
     const int j = lane & 15;
-    double e[16], rv[16];
+    double e[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = Pd[r * LDT + j];
     // this wave is the youngest of its SIMD and would lose every issue arbitration against the MFMA streams of the
     // update waves beside it (priority, then age); its chain is what the whole workgroup waits for
     __builtin_amdgcn_s_setprio(3);
+    // Instruction count is what bounds this routine (the wave shares its SIMD with two MFMA-streaming update waves, so every
+    // VALU slot is contended): per (pivot k, row r) TWO v_readlane (entry A[r][k] of lane k into an SGPR pair) and ONE fma
+    //   e[r] -= A[r][k] * (U[k][j] / piv)        with the bracket formed once per pivot, zero in the lanes j <= k,
+    // and the multipliers of column k (lane k's entries below the diagonal, untouched by later pivots) scaled by the lane's
+    // own reciprocal pivot at the end.  Was: mul + 2 readlane + fma + selects per (k, r): ~1100 instructions, 20.8 k cycles.
+    double myrinv = 1.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e[k]), k),
@@ -1009,26 +1015,23 @@ __device__ __forceinline__ void tile_lu_regs(int s, double *Pd, double *rd, int 
         double rinv = __builtin_amdgcn_rcp(piv);
         rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
         rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
-        rv[k] = rinv;
-        const double uk = e[k];                                    // U[k][j] (final for j >= k)
+        if (lane == 0) rd[k] = rinv;                               // reciprocal pivots for the division-free panel solves
+        if (j == k) myrinv = rinv;
+        const double ukr = (j > k) ? e[k] * rinv : 0.0;           // U[k][j] / piv (final U[k][j] stays in e[k])
 #pragma unroll
         for (int r = k + 1; r < 16; ++r) {
-            // multiplier l[r] = A[r][k] / pivot: computed in lane k, read by everybody
-            const double lk = e[r] * rinv;
-            const double l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lk), k),
-                                              __builtin_amdgcn_readlane(__double2loint(lk), k));
-            if (j > k) e[r] = fma(-l, uk, e[r]);
-            else if (j == k) e[r] = l;                             // the multiplier replaces the eliminated entry
+            const double ark = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e[r]), k),
+                                                __builtin_amdgcn_readlane(__double2loint(e[r]), k));
+            e[r] = fma(-ark, ukr, e[r]);
         }
     }
+#pragma unroll
+    for (int r = 1; r < 16; ++r)
+        if (r > j) e[r] *= myrinv;                                 // L[r][j] = A[r][j] / U[j][j]
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (lane < 16) Pd[r * LDT + j] = e[r];
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) rd[k] = rv[k];
-    }
 }
 
 // panel solves of one block step, division-free (rd = reciprocal pivots left by tile_lu_regs):
@@ -1221,14 +1224,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
             double la[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) la[q] = -Lp[4 * q];
+            // U operands two tiles at a time (the reads of the next pair are in flight while this pair's MFMAs issue)
 #pragma unroll
             for (int b = 0; b < KB; ++b) {
                 const int J = (b - as - 1 + KB) % KB + 1;
                 if ((I == 1 && J == 1) != diag_only) continue;
                 const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
+                double u[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[q] = Up[4 * q * LDT];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[rr][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], Up[4 * q * LDT], acc[rr][b], 0, 0, 0);
+                    acc[rr][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], u[q], acc[rr][b], 0, 0, 0);
+                if (b & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };

@@ -118,7 +118,9 @@ int spike_setup_band(spike_handle h, int64_t n_global, int64_t row0, int64_t n_l
 
 /* CSR entry (single rank): band extraction with the reference's rule, then spike_setup_band.
  * kmax/frac as PCBANDED's -pc_banded_kmax/-pc_banded_frac (defaults 50 / 0.95).
- * ia/ja are 0-based int64 host arrays.                                                     */
+ * ia/ja are 0-based int64 host arrays.  Precondition (what an assembled AIJ matrix gives, MatGetRow at matbanded.c:40):
+ * a row holds a column at most once.  A repeated (row, column) pair is summed on the device with fp64 atomics, i.e. in
+ * no fixed order: the band then agrees with the sequential sum to rounding only, not bit for bit.            */
 int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
                     int kmax, double frac, int *k_out, double *frac_out);
 

@@ -22,7 +22,7 @@ int spike_csr_band_k(int64_t n, const int64_t *ia, const int64_t *ja, const doub
 int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int K, double *band, int64_t ld);
 
 /* ---------------------------------------------------------------------------------------------------- */
-static char g_err[512];
+static _Thread_local char g_err[512];   /* per thread, like errno: two threads driving two solvers do not overwrite each other's text */
 const char *SpikeHostLastError(void) { return g_err; }
 static PetscErrorCode seterr(PetscErrorCode code, const char *fmt, ...)
 {
@@ -35,37 +35,60 @@ static PetscErrorCode seterr(PetscErrorCode code, const char *fmt, ...)
 #define CHK(e) do { PetscErrorCode ierr_ = (e); if (ierr_) return ierr_; } while (0)
 
 /* ---- options --------------------------------------------------------------------------------------- */
+/* one process-wide table, as PETSc's default options database; every access under one lock, look-ups return a copy */
+#include <pthread.h>
 #define MAXOPT 256
 static struct { char name[128]; char val[128]; } g_opt[MAXOPT];
 static int g_nopt = 0;
+static pthread_mutex_t g_opt_lock = PTHREAD_MUTEX_INITIALIZER;
 
 PetscErrorCode PetscOptionsSetValue(const char *name, const char *value)
 {
     if (!name || name[0] != '-') return seterr(PETSC_ERR_ARG_WRONG, "option names start with '-'");
-    for (int i = 0; i < g_nopt; ++i)
-        if (!strcmp(g_opt[i].name, name)) { snprintf(g_opt[i].val, sizeof g_opt[i].val, "%s", value ? value : ""); return 0; }
-    if (g_nopt >= MAXOPT) return seterr(PETSC_ERR_MEM, "options table full");
-    snprintf(g_opt[g_nopt].name, sizeof g_opt[g_nopt].name, "%s", name);
-    snprintf(g_opt[g_nopt].val, sizeof g_opt[g_nopt].val, "%s", value ? value : "");
-    ++g_nopt;
-    return 0;
+    PetscErrorCode rc = 0;
+    pthread_mutex_lock(&g_opt_lock);
+    int i = 0;
+    for (; i < g_nopt; ++i)
+        if (!strcmp(g_opt[i].name, name)) { snprintf(g_opt[i].val, sizeof g_opt[i].val, "%s", value ? value : ""); break; }
+    if (i == g_nopt) {
+        if (g_nopt >= MAXOPT) rc = PETSC_ERR_MEM;
+        else {
+            snprintf(g_opt[g_nopt].name, sizeof g_opt[g_nopt].name, "%s", name);
+            snprintf(g_opt[g_nopt].val, sizeof g_opt[g_nopt].val, "%s", value ? value : "");
+            ++g_nopt;
+        }
+    }
+    pthread_mutex_unlock(&g_opt_lock);
+    return rc ? seterr(rc, "options table full") : 0;
 }
 PetscErrorCode PetscOptionsClearValue(const char *name)
 {
+    pthread_mutex_lock(&g_opt_lock);
     for (int i = 0; i < g_nopt; ++i)
-        if (!strcmp(g_opt[i].name, name)) { g_opt[i] = g_opt[g_nopt - 1]; --g_nopt; return 0; }
+        if (!strcmp(g_opt[i].name, name)) { g_opt[i] = g_opt[g_nopt - 1]; --g_nopt; break; }
+    pthread_mutex_unlock(&g_opt_lock);
     return 0;
 }
-PetscErrorCode PetscOptionsClear(void) { g_nopt = 0; return 0; }
+PetscErrorCode PetscOptionsClear(void)
+{
+    pthread_mutex_lock(&g_opt_lock);
+    g_nopt = 0;
+    pthread_mutex_unlock(&g_opt_lock);
+    return 0;
+}
 
-/* "-<prefix><key>" */
+/* "-<prefix><key>": the value copied into a per-thread buffer (valid until the thread's next look-up) */
 static const char *opt_find(const char *prefix, const char *key)
 {
+    static _Thread_local char val[128];
     char full[256];
+    const char *r = NULL;
     snprintf(full, sizeof full, "-%s%s", prefix ? prefix : "", key);
+    pthread_mutex_lock(&g_opt_lock);
     for (int i = 0; i < g_nopt; ++i)
-        if (!strcmp(g_opt[i].name, full)) return g_opt[i].val;
-    return NULL;
+        if (!strcmp(g_opt[i].name, full)) { memcpy(val, g_opt[i].val, sizeof val); r = val; break; }
+    pthread_mutex_unlock(&g_opt_lock);
+    return r;
 }
 static void opt_int(const char *prefix, const char *key, PetscInt *v) { const char *s = opt_find(prefix, key); if (s) *v = (PetscInt)atoll(s); }
 static void opt_real(const char *prefix, const char *key, PetscReal *v) { const char *s = opt_find(prefix, key); if (s) *v = atof(s); }

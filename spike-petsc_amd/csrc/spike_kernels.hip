@@ -1106,12 +1106,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     unsigned long long nb = 0;
     // diagnostic build of the schedule (stamps != nullptr, SPIKE_FACTOR_STAMPS=1): shader-clock stamps of workgroup 0 at the
     // phase boundaries of steps 64..71, slot = (step - 64) * 16 + wave_kind * 8 + point; never set in normal runs
-    auto stamp = [&](int s, int point) {
+    auto stamp = [&](int s, int point) __attribute__((always_inline)) {
         if (stamps != nullptr && blockIdx.x == 0 && lane == 0 && (w == 0 || w == NW) && s >= 64 && s < 72)
             stamps[(s - 64) * 16 + (w == NW ? 8 : 0) + point] = __builtin_amdgcn_s_memtime();
     };
 
-    auto ldA = [&](int rb, int cb, int row, int col) -> double {
+    auto ldA = [&](int rb, int cb, int row, int col) __attribute__((always_inline)) -> double {
         const int r = 16 * rb + row, c = 16 * cb + col;  // partition-local
         if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;  // identity padding past the partition end
         return lu_get(lv, rs, r, c);
@@ -1119,21 +1119,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     // a tile that lies inside the chain and inside the scratch is 2 KiB contiguous, and (row = (lane>>4) + 4q, col = lane&15)
     // is element lane + 64 q of it: four fully coalesced 512-byte loads, one scalar base address per tile
     const int64_t rbg0 = rs >> 4;
-    auto tile_inside = [&](int rb, int cb) -> bool {
+    auto tile_inside = [&](int rb, int cb) __attribute__((always_inline)) -> bool {
         return 16 * (rb + 1) <= np && 16 * (cb + 1) <= np && cb - rb + lv.KB >= 0 && cb - rb + lv.KB < lv.ntl;
     };
-    auto tile_base = [&](int rb, int cb) -> double * { return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256; };
-    auto load_tile = [&](v4d &t, int rb, int cb) {
-        if (tile_inside(rb, cb)) {
-            const double *tp = tile_base(rb, cb) + lane;
+    auto tile_base = [&](int rb, int cb) __attribute__((always_inline)) -> double * { return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256; };
+    auto load_tile = [&](v4d &t, int rb, int cb, auto fc) __attribute__((always_inline)) {
+        if (decltype(fc)::value || tile_inside(rb, cb)) {
+            const double *tp = tile_base(rb, cb);   // wave-uniform base (scalar registers) + the lane as a 32-bit index: a
+                                                    // per-lane 64-bit pointer per tile was what the kernel spilled
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q];
+            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q + lane];
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
         }
     };
-    auto store_tile = [&](const v4d &t, double *dst) {
+    auto store_tile = [&](const v4d &t, double *dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
     };
@@ -1143,58 +1144,63 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-            for (int b = 0; b < KB; ++b) load_tile(acc[rr][b], rr * NW + w, b);
+            for (int b = 0; b < KB; ++b) load_tile(acc[rr][b], rr * NW + w, b, std::false_type{});
     }
 
     // the two panel tiles of step sx that never enter the window, (sx+KB, sx) and (sx, sx+KB): raw band entries, fetched
     // into registers one step ahead and put into the panel buffer when that panel is extracted
     double xt[NX];
-    auto fetch_extra = [&](int sx) {
-        const bool in0 = tile_inside(sx + KB, sx), in1 = tile_inside(sx, sx + KB);
+    auto fetch_extra = [&](double (&xd)[NX], int sx, auto fc) __attribute__((always_inline)) {
+        const bool in0 = decltype(fc)::value || tile_inside(sx + KB, sx), in1 = decltype(fc)::value || tile_inside(sx, sx + KB);
         const double *b0 = in0 ? tile_base(sx + KB, sx) : lv.p, *b1 = in1 ? tile_base(sx, sx + KB) : lv.p;
 #pragma unroll
         for (int q = 0; q < NX; ++q) {
             const int e = tid + q * NTU;      // update threads only: the panel wave is busy with the LU when this runs
             const int row = (e >> 4) & 15, col = e & 15;
-            if (e >= 512 || !upd) xt[q] = 0.0;
-            else if ((e >> 8) == 0) xt[q] = in0 ? b0[e & 255] : ldA(sx + KB, sx, row, col);
-            else xt[q] = in1 ? b1[e & 255] : ldA(sx, sx + KB, row, col);
+            if (e >= 512 || !upd) xd[q] = 0.0;
+            else if ((e >> 8) == 0) xd[q] = in0 ? b0[e & 255] : ldA(sx + KB, sx, row, col);
+            else xd[q] = in1 ? b1[e & 255] : ldA(sx, sx + KB, row, col);
         }
     };
     // panel of step s: registers -> LDS buffer P; the freed slots take the entering tiles
-    auto extract = [&](int s, double *P, int mode) {   // mode 0: everything, 1: the diagonal tile only, 2: all but it
+    auto extract = [&](int s, double *P, int mode, auto fc) __attribute__((always_inline)) {   // mode 0: everything, 1: the diagonal tile only, 2: all but it
         double *Pd = P, *Pc = P + TS, *Pr = P + TS + KB * TS;
         const int as = s % KB;
         // Entering tiles: block row s+KB (tiles (s+KB, s+1 .. s+KB): slots 1 .. KB of that row block, 16 KiB contiguous) and
         // block column s+KB (tile (s+I, s+KB): slot 2KB - I of row block s+I).  They all lie inside the chain iff block
         // s+KB does -- ONE uniform test for the whole step instead of bounds logic per tile (the wave that owns the pivot
         // row moves eight tiles here: it was the slowest wave of every step).
-        const bool fast = 16 * (s + KB + 1) <= np;
-        const double *rowbase = lv.p + ((rbg0 + s + KB) * lv.ntl) * 256 + lane;
+        const bool fast = decltype(fc)::value || 16 * (s + KB + 1) <= np;
+        const double *rowbase = lv.p + ((rbg0 + s + KB) * lv.ntl) * 256;
+        // ONE store site and ONE load site per accumulator tile, source and destination chosen by wave-uniform selects, and
+        // all stores of the step BEFORE its first load.  With a load in each of two branches the compiler merged them through
+        // temporaries and waited for every tile's loads on the spot; with store and load of a tile next to each other its
+        // wait-count bookkeeping (registers with a load pending from the previous trip round the loop) made the store of
+        // tile k wait for the loads of tile k-2: the wave that owns the panel row (eight tiles) spent 21 k cycles in this
+        // phase, everybody else 12 k.
         if (upd) {
 #pragma unroll
-            for (int rr = 0; rr < RPW; ++rr) {
-                const int a = rr * NW + w;
+            for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                for (int b = 0; b < KB; ++b) {
-                    const bool isdiag = a == as && b == as;
-                    if ((mode == 1 && !isdiag) || (mode == 2 && isdiag)) continue;
-                    if (a == as) {
-                        const int J = (b - as + KB) % KB;  // tile (s, s+J)
-                        store_tile(acc[rr][b], J == 0 ? Pd : Pr + (J - 1) * TS);
-                        const int Jn = (b - as - 1 + KB) % KB + 1;  // new tile (s+KB, s+Jn)
-                        if (fast) {
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const int a = rr * NW + w;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[rr][b][q] = rowbase[Jn * 256 + 64 * q];
-                        } else load_tile(acc[rr][b], s + KB, s + Jn);
-                    } else if (b == as) {
-                        const int I = (a - as + KB) % KB;  // tile (s+I, s), I in 1..KB-1
-                        store_tile(acc[rr][b], Pc + (I - 1) * TS);
-                        if (fast) {                            // new tile (s+I, s+KB)
-                            const double *cb = lv.p + ((rbg0 + s + I) * lv.ntl + (2 * KB - I)) * 256 + lane;
+                    for (int b = 0; b < KB; ++b) {
+                        const bool isdiag = a == as && b == as;
+                        if ((mode == 1 && !isdiag) || (mode == 2 && isdiag)) continue;
+                        const bool isrow = a == as, iscol = !isrow && b == as;
+                        if (!isrow && !iscol) continue;
+                        const int J = (b - as + KB) % KB;           // row tile (s, s+J)
+                        const int Jn = (b - as - 1 + KB) % KB + 1;  // its successor (s+KB, s+Jn)
+                        const int I = (a - as + KB) % KB;           // column tile (s+I, s), I in 1..KB-1; successor (s+I, s+KB)
+                        if (pass == 0) {
+                            double *dst = isrow ? (J == 0 ? Pd : Pr + (J - 1) * TS) : Pc + (I - 1) * TS;
+                            store_tile(acc[rr][b], dst);
+                        } else if (fast) {
+                            const double *src = isrow ? rowbase + Jn * 256 : lv.p + ((rbg0 + s + I) * lv.ntl + (2 * KB - I)) * 256;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[rr][b][q] = cb[64 * q];
-                        } else load_tile(acc[rr][b], s + I, s + KB);
+                            for (int q = 0; q < 4; ++q) acc[rr][b][q] = src[64 * q + lane];
+                        } else load_tile(acc[rr][b], isrow ? s + KB : s + I, isrow ? s + Jn : s + KB, std::false_type{});
                     }
                 }
             }
@@ -1212,7 +1218,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     };
     // trailing update of step s from panel buffer P: tile(s+I, s+J) -= L21[I] * U12[J]; diag_only: just the next diagonal
     // tile (I == J == 1), else everything but it
-    auto update = [&](int s, const double *P, bool diag_only) {
+    auto update = [&](int s, const double *P, bool diag_only) __attribute__((always_inline)) {
         const double *Pc = P + TS, *Pr = P + TS + KB * TS;
         const int as = s % KB;
 #pragma unroll
@@ -1248,7 +1254,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     // Two LDS round trips per tile (load, store) instead of one per pivot (first round-2 version: 700 cycles per pivot
     // alone, 1400 beside the update waves) or four to five plus an IEEE divide (round 1: 1100).  The reciprocal pivot is
     // v_rcp_f64 + two Newton steps.
-    auto panel_lu = [&](int s, double *Pd, double *rd) { tile_lu_regs(s, Pd, rd, np, boost, nb, lane); };
+    auto panel_lu = [&](int s, double *Pd, double *rd) __attribute__((always_inline)) { tile_lu_regs(s, Pd, rd, np, boost, nb, lane); };
 
     // Schedule (three barriers per step):
     //   P1(s)  everybody: the panel solves of step s (division-free: the LU left the reciprocal pivots)
@@ -1256,17 +1262,18 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     //   P3(s)  panel wave: LU of that tile  ||  update waves: the rest of the trailing update of step s, the rest of
     //          panel s+1 to the other buffer (freed slots refilled with the entering tiles), the write-back of step s
     // so the 16 serial pivots of step s+1 hide behind everything else of step s.
-    fetch_extra(0);
-    extract(0, lds, 0);
-    fetch_extra(1);
+    fetch_extra(xt, 0, std::false_type{});
+    extract(0, lds, 0, std::false_type{});
+    fetch_extra(xt, 1, std::false_type{});
     __syncthreads();
     if (!upd) panel_lu(0, lds, rdiag);
     __syncthreads();
-    for (int s = 0; s < nblk; ++s) {
+    auto block_step = [&](int s, auto fc) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fc)::value;
         double *cur = lds + (s & 1) * PSZ, *nxt = lds + ((s + 1) & 1) * PSZ;
         double *Pd = cur, *Pc = cur + TS, *Pr = cur + TS + KB * TS;
         const double *rd = rdiag + (s & 1) * 16;
-        const bool more = s + 1 < nblk;
+        const bool more = FAST || s + 1 < nblk;
         // ---- P1(s): L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
         stamp(s, 0);
         panel_solves<KB, NT>(Pd, Pc, Pr, rd, tid);
@@ -1276,7 +1283,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
         // ---- P2(s)
         if (more && upd) {
             update(s, cur, true);
-            extract(s + 1, nxt, 1);
+            extract(s + 1, nxt, 1, fc);
         }
         stamp(s, 3);
         __syncthreads();
@@ -1286,12 +1293,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
             if (more) panel_lu(s + 1, nxt, rdiag + ((s + 1) & 1) * 16);
             stamp(s, 5);
         } else {
-            if (more) {
-                update(s, cur, false);
-                extract(s + 1, nxt, 2);
-                fetch_extra(s + 2);
-            }
-            stamp(s, 5);
+            // The write-back comes FIRST: the entering-tile loads of extract() must be the youngest vector-memory operations
+            // of the step -- anything issued after them that the wave has to wait for (a store's address reload from the
+            // spill area is enough: vector-memory operations return in order) would pay their whole global round trip.
             // write the finished block row / block column back: a tile inside the chain is 2 KiB contiguous in the
             // scratch; the 2 KB+1 tiles are dealt to the update waves, a tile = 4 LDS reads + 4 coalesced 512-byte stores
             for (int tile = w; tile <= 2 * KB; tile += NW) {
@@ -1303,10 +1307,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
                 double v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = T[((lane >> 4) + 4 * q) * LDT + (lane & 15)];
-                if (tile_inside(rb, cb)) {
-                    double *tp = tile_base(rb, cb) + lane;
+                if (FAST || tile_inside(rb, cb)) {
+                    double *tp = tile_base(rb, cb);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) tp[64 * q] = v[q];
+                    for (int q = 0; q < 4; ++q) tp[64 * q + lane] = v[q];
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1315,11 +1319,31 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
                     }
                 }
             }
+            stamp(s, 5);
+            if (more) {
+                // the two raw panel tiles of step s+2 are requested BEFORE the entering-tile loads of extract(): whatever
+                // waits for them afterwards (their copy, or their way into a spill slot) then does not wait for the eight
+                // younger tile loads as well (vector-memory operations return in order)
+                double xn[NX];
+                fetch_extra(xn, s + 2, fc);
+                update(s, cur, false);
+                extract(s + 1, nxt, 2, fc);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) xt[q] = xn[q];
+            }
         }
         stamp(s, 6);
         __syncthreads();
         stamp(s, 7);
-    }
+    };
+    // Interior steps touch only tiles that lie inside the chain (step s reaches block s + KB + 2 at most): a loop of their
+    // own, compiled without the element-wise edge paths -- whose loop-invariant per-lane indices otherwise stay live across
+    // the hot loop and pushed it into spills (a reload costs a memory round trip on the critical wave).  The last
+    // KB + 2 steps of a chain take the general body.
+    const int sfast = np / 16 - KB - 2;
+    int s0 = 0;
+    for (; s0 < sfast; ++s0) block_step(s0, std::true_type{});
+    for (; s0 < nblk; ++s0) block_step(s0, std::false_type{});
     if (lane == 0 && !upd && nb) atomicAdd(nboost, nb);
 }
 
@@ -1345,7 +1369,7 @@ static hipError_t launch_factor_mfma_la_t(const LuView &lv, const ChainDesc *cha
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(hs, stamps, sizeof hs, hipMemcpyDeviceToHost);
         (void)hipFree(stamps);
-        const char *names[7] = {"P1: panel solves", "barrier", "P2: next diag tile", "barrier", "P3: LU | upd+extract", "P3: write-back", "barrier"};
+        const char *names[7] = {"P1: panel solves", "barrier", "P2: next diag tile", "barrier", "P3: LU | write-back", "P3: upd+extract", "barrier"};
         for (int kind = 0; kind < 2; ++kind) {
             fprintf(stderr, "[factor stamps] %s wave, shader cycles per phase, steps 64..71:\n", kind ? "panel" : "update");
             for (int ph = 0; ph < 7; ++ph) {
@@ -1745,7 +1769,6 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
     const int64_t i0 = cd.row0 + (int64_t)sb * R;
     const int rows_here = (cd.nrows - sb * R) < R ? (cd.nrows - sb * R) : R;
     const bool rowok = r < rows_here;
-    const int Kn = K < R - 1 ? K : R - 1;
     double di = 1.0;
     const int rl = sb * R + (rowok ? r : 0);                   // chain-local row of this lane (clamped)
     if (UPPER && rowok) {

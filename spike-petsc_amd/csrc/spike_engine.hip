@@ -171,6 +171,11 @@ struct spike_handle_s {
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
+    // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
+    // (the 26 KiB of interface descriptors at 256 chains is) makes the FIRST such copy of a process build the runtime's
+    // own staging pool: 15 ms inside hipMemcpyAsync, a third of a headline setup.
+    char *hPin = nullptr;
+    size_t pinCap = 0, pinOff = 0;
     double *dAtOp = nullptr;                              // tile-major copy of a separate banded operator (spike_set_operator_band)
     // optional CSR operator for the Krylov solver (A != band: the reference preconditions A with its band)
     bool use_kept_band = false;  // spike_band_matvec: bypass the optional operators
@@ -327,12 +332,40 @@ static void free_factors(spike_handle h)
     h->groups.clear();
 }
 
+// Descriptor upload (a few KiB of structs per call).  The first host-to-device copy of a process that is larger than the
+// runtime's small-copy limit spends 15 ms inside hipMemcpyAsync bringing up the copy-engine path -- pinned source or not
+// (measured: the 26 KiB of interface descriptors of a 256-chain setup) -- a third of a headline setup.  So descriptors go
+// through the handle's pinned, device-mapped staging area and a copy KERNEL reads them from there (zero-copy), ~10 us.
+__global__ void k_copy_words(uint32_t *dst, const uint32_t *src, size_t nwords)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static hipError_t upload(spike_handle h, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > h->pinCap || (bytes & 3) != 0) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    if (h->pinOff + need > h->pinCap) {          // area used up: wait for the copies in flight, start over
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        h->pinOff = 0;
+    }
+    memcpy(h->hPin + h->pinOff, src, bytes);
+    const size_t nw = bytes / 4;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((nw + 255) / 256 < 64 ? (nw + 255) / 256 : 64)), dim3(256), 0, st, (uint32_t *)dst,
+                       (const uint32_t *)(h->hPin + h->pinOff), nw);
+    h->pinOff += need;
+    return hipGetLastError();
+}
+
 extern "C" int spike_create(spike_handle *out)
 {
     if (!out) return SPIKE_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { *out = nullptr; return SPIKE_ERR_HIP; }
     *out = new spike_handle_s();
+    (*out)->pinCap = (size_t)1 << 20;   // the pinned staging area of upload(), made here so that no setup pays for it
+    if (hipHostMalloc((void **)&(*out)->hPin, (*out)->pinCap, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (*out)->hPin = nullptr; (*out)->pinCap = 0; }
     return SPIKE_OK;
 }
 
@@ -355,6 +388,7 @@ extern "C" int spike_destroy(spike_handle h)
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->hPin) (void)hipHostFree(h->hPin);
     for (int i = 0; i < 2; ++i) if (h->evDots[i]) (void)hipEventDestroy(h->evDots[i]);
     delete h;
     return SPIKE_OK;
@@ -696,6 +730,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     free_factors(h);
     TmpPool tmp;
     const auto t_start = std::chrono::steady_clock::now();
+    h->pinOff = 0;   // every copy of the previous setup has completed (setup ends with a synchronisation)
     // SPIKE_SETUP_TRACE=1: wall time of every setup phase on stderr (synchronises the stream at phase boundaries)
     const bool trace = getenv("SPIKE_SETUP_TRACE") != nullptr;
     auto t_mark = t_start;
@@ -757,8 +792,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     }
     HIPCHK(dalloc(&h->dChains, (size_t)P));
     HIPCHK(dalloc(&h->dGroups, h->groups.size()));
-    HIPCHK(hipMemcpyAsync(h->dChains, h->chains.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(upload(h, h->dChains, h->chains.data(), sizeof(ChainDesc) * P, st));
+    HIPCHK(upload(h, h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), st));
 
     mark("band copy");
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
@@ -863,12 +898,12 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             GroupDesc *dG[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < 2; ++i) HIPCHK(tmp.alloc(&dC[i], (size_t)P));
             for (int i = 0; i < 4; ++i) HIPCHK(tmp.alloc(&dG[i], (size_t)P));
-            HIPCHK(hipMemcpyAsync(dC[0], ct.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dC[1], cb.data(), sizeof(ChainDesc) * P, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dG[0], gtF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dG[1], gtB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dG[2], gbF.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dG[3], gbB.data(), sizeof(GroupDesc) * P, hipMemcpyHostToDevice, st));
+            HIPCHK(upload(h, dC[0], ct.data(), sizeof(ChainDesc) * P, st));
+            HIPCHK(upload(h, dC[1], cb.data(), sizeof(ChainDesc) * P, st));
+            HIPCHK(upload(h, dG[0], gtF.data(), sizeof(GroupDesc) * P, st));
+            HIPCHK(upload(h, dG[1], gtB.data(), sizeof(GroupDesc) * P, st));
+            HIPCHK(upload(h, dG[2], gbF.data(), sizeof(GroupDesc) * P, st));
+            HIPCHK(upload(h, dG[3], gbB.data(), sizeof(GroupDesc) * P, st));
             HIPCHK(hipStreamSynchronize(st));   // the host vectors go out of scope
             top.chains = dC[0]; top.groupsF = dG[0]; top.groupsB = dG[1];
             bot.chains = dC[1]; bot.groupsF = dG[2]; bot.groupsB = dG[3];
@@ -1090,7 +1125,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         }
         for (auto &d : ifs) { d.xb_out = nullptr; d.xt_out = nullptr; }
         HIPCHK(dalloc(&h->dIfs, (size_t)nif));
-        HIPCHK(hipMemcpyAsync(h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+        HIPCHK(upload(h, h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, st));
         // cuts inside a caller partition stay coupled even in the decoupled (block-Jacobi) variant
         std::vector<int> internal;
         if (h->S > 1)
@@ -1101,7 +1136,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             std::vector<IfaceDesc> ii;
             for (int i : internal) ii.push_back(ifs[i]);
             HIPCHK(dalloc(&h->dIfsInt, ii.size()));
-            HIPCHK(hipMemcpyAsync(h->dIfsInt, ii.data(), sizeof(IfaceDesc) * ii.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(upload(h, h->dIfsInt, ii.data(), sizeof(IfaceDesc) * ii.size(), st));
             HIPCHK(hipStreamSynchronize(st));
         }
         if (h->spike_m > 0) {
@@ -1119,12 +1154,12 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (ib_prev >= 0) { ff[ib_prev].xb_out = h->dXb; ff[ib_prev].xt_out = h->dXt + (size_t)K; }
             if (ib_next >= 0) { ff[ib_next].xb_out = h->dXb + (size_t)P * K; ff[ib_next].xt_out = h->dXt + (size_t)(P + 1) * K; }
             HIPCHK(dalloc(&h->dIfsFast, (size_t)nif));
-            HIPCHK(hipMemcpyAsync(h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, hipMemcpyHostToDevice, st));
+            HIPCHK(upload(h, h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, st));
             if (h->nif_int > 0) {
                 std::vector<IfaceDesc> fi;
                 for (int i : internal) fi.push_back(ff[i]);
                 HIPCHK(dalloc(&h->dIfsFastInt, fi.size()));
-                HIPCHK(hipMemcpyAsync(h->dIfsFastInt, fi.data(), sizeof(IfaceDesc) * fi.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(upload(h, h->dIfsFastInt, fi.data(), sizeof(IfaceDesc) * fi.size(), st));
                 HIPCHK(hipStreamSynchronize(st));
             }
         }

@@ -618,7 +618,11 @@ static void pick_sweep_shape(spike_handle h, int ncu)
         if (sscanf(e, "%d,%d,%d", &d, &w, &f) == 3 && sweep_shape_exists(c, d, w, f)) { c.sDPW = d; c.sNW = w; c.sPF = f; }
         return;
     }
-    (void)ncu;
+    // 16 < K <= 32 with few workgroups (BASELINE config 2: 512 chains = 256 one-wave workgroups): four waves of 8 diagonals
+    // per chain pair, four bundles each -- the same bytes in flight per CU from lighter waves whose LDS round trips hide
+    // each other: 0.133 -> 0.127 ms per apply (tools/r2_c2shapes.sh; 16 x 2 the same, the one-wave shapes with deeper
+    // prefetch are slower: their bundles no longer fit the VGPRs)
+    if (c.R == 32 && (int64_t)h->groups.size() <= 2 * (int64_t)ncu && sweep_shape_exists(c, 8, 4, 4)) { c.sDPW = 8; c.sNW = 4; c.sPF = 4; }
     // two waves per chain (32 < K <= 64): four bundles in flight per wave instead of two (the workgroup is small, the
     // registers are there): 1.46 -> 1.38 ms per pass at N = 8M, K = 64
     if (c.R == 64 && c.NW == 2 && sweep_shape_exists(c, 32, 2, 4)) { c.sDPW = 32; c.sNW = 2; c.sPF = 4; }

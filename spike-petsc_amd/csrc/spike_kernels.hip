@@ -272,7 +272,7 @@ static hipError_t launch_sweep_a(bool rev, int ngroups, const SweepArgs &a, hipS
 
 // shape list (R, DPW, NW, PF) beyond the base shapes; X(R, DPW, NW, PF)
 #define SPIKE_ALT_SHAPES(X)                                                                          \
-    X(32, 8, 4, 4) X(32, 16, 2, 3)                                                                   \
+    X(32, 8, 4, 4) X(32, 16, 2, 3) X(32, 16, 2, 4) X(32, 16, 2, 6) X(32, 32, 1, 3) X(32, 32, 1, 4) X(32, 8, 4, 8) \
     X(64, 32, 2, 4) X(64, 32, 3, 4) X(64, 32, 4, 4)                                                  \
     X(64, 16, 4, 2) X(64, 16, 4, 4) X(64, 16, 6, 2) X(64, 16, 6, 4) X(64, 16, 8, 2) X(64, 16, 8, 4)  \
     X(64, 16, 12, 2) X(64, 16, 12, 3) X(64, 16, 16, 2) X(64, 16, 16, 3)

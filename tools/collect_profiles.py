@@ -10,12 +10,13 @@ import sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = "profiles"
-for name in ["bench", "n2097152", "n1048576", "n524288", "c2"]:
+for name in ["bench", "n2097152", "n1048576", "n524288", "c2", "fiedler"]:
     f = glob.glob(os.path.join(src, "stats_" + name, "*", "*_kernel_stats.csv"))
     if f:
         shutil.copy(f[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
 for name in ["bench_line.json", "bench_line_under_rocprof.json", "pmc_summary.json", "rank_n2097152.json", "rank_n1048576.json",
-             "rank_n524288.json", "c2.json"]:
+             "rank_n524288.json", "c2.json", "rank_n524288_rccl_overlap.json", "fiedler_trace.log", "config4_timing.log",
+             "setup_trace_k128.log"]:
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))

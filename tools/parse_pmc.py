@@ -25,15 +25,19 @@ def main(fetch_dir, write_dir, out, note=""):
     for k in f:
         if not k.startswith(("spike::", "void spike::", "k_")):
             continue
-        fv = [x[0] for x in f[k]]
-        wv = [x[0] for x in w.get(k, [(0.0, 0.0)])]
+        fv = sorted(x[0] for x in f[k])
+        wv = sorted(x[0] for x in w.get(k, [(0.0, 0.0)]))
+        med = lambda v: v[len(v) // 2]
+        # per launch = the MEDIAN over the launches of the run: bench.py's warm-up setup (64 K rows) also launches the apply
+        # kernels once, which would drag a mean down (the timed launches all have the same size)
         res["kernels"][k] = {
             "launches": len(fv),
+            "FETCH_SIZE_KiB_median": med(fv),
+            "WRITE_SIZE_KiB_median": med(wv),
             "FETCH_SIZE_KiB_mean": sum(fv) / len(fv),
-            "WRITE_SIZE_KiB_mean": sum(wv) / len(wv),
-            "hbm_read_bytes_corrected": 2.0 * 1024.0 * sum(fv) / len(fv),
-            "hbm_write_bytes": 1024.0 * sum(wv) / len(wv),
-            "avg_duration_us_under_pmc": sum(x[1] for x in f[k]) / len(fv),
+            "hbm_read_bytes_corrected": 2.0 * 1024.0 * med(fv),
+            "hbm_write_bytes": 1024.0 * med(wv),
+            "median_duration_us_under_pmc": med(sorted(x[1] for x in f[k])),
         }
     json.dump(res, open(out, "w"), indent=1)
     print("wrote", out)

@@ -1760,7 +1760,7 @@ __device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
 }
 
 template <bool UPPER>
-__device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const LuView &lv, int K,
+__device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis, int DPW, int NW, const LuView &lv, int K,
                                             const ChainDesc &cd, int sb, double *T, double *dinv)
 {
     constexpr int R = 64;
@@ -1775,6 +1775,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
         di = 1.0 / lu_get(lv, cd.row0, rl, rl);
         dinv[i0 + r] = di;
     }
+    if (UPPER) dis[r] = di;                                     // 1/U_rr by block row, for the strip phase below
     // Ms[q][c] (row-major square): strict lower triangle = in-block entries (flipped row/column order for UPPER).
     // The lane's row of the 64 x 64 diagonal block is 4 x 128 contiguous bytes of the block-band scratch: all 32 16-byte
     // loads are issued unconditionally and back to back (one memory latency), the triangle is selected afterwards.
@@ -1807,32 +1808,97 @@ __device__ __forceinline__ void pack64_side(double *Ms, int DPW, int NW, const L
     }
     WAVE_LDS_FENCE();
     invert_unit_lower_64(Ms, lane);   // the strictly lower triangle of Ms now holds that of M^{-1}
-    // tile rows: lane = tile lane; entry d: in-block (d <= lane) = -X[lane][lane-d], else the band entry d rows/columns away
-    // Every load is unconditional (clamped address, result selected afterwards) and the 16 entries of a wave slice are
-    // unrolled, so the loads of a slice are in flight together.  (Measured: neither this nor the batched substitution
-    // changes the kernel's 14 ms -- what bounds it is the gather of 257 band diagonals, 512 B from each, per row block.)
-    constexpr int NLD = 16;   // DPW = 32 for every R = 64 configuration
+    // The tile is written 16 rows at a time.  Entry d of tile lane L (row L of the block; flipped for the upper factor):
+    // in-block (d <= L) = -X[L][L-d] from Ms, else the band entry d columns away -- the FAR part, K entries per row that
+    // lie in the KBv 16 x 16 scratch tiles beside the diagonal block.  Those tiles are brought in whole (two coalesced
+    // 1-KiB loads each) into the LDS strip Fs and picked from there with lane = (row in the strip, slot group).  Round 1/2a
+    // gathered them with lane = row, one 8-byte load per (row, d): every load instruction touched 64 different 128-byte
+    // lines, 128 instructions per side, and the L1 asked the L2 four times for every line (PMC) -- 11.4 ms for a kernel that
+    // moves 17.7 GB.
     (void)DPW;
+    const int KBv = (K + 15) >> 4;                             // far tiles per strip, at most
+    const int FS = 16 * KBv + 1;                               // strip row stride (odd: FS + 1 = 2 mod 16 -> no bank conflicts)
+    const int row16 = lane & 15, q = lane >> 4;
+    const int nblk16 = (cd.nrows + 15) >> 4;
     d2 *T2 = reinterpret_cast<d2 *>(T);
-    auto val = [&](int d) -> double {
-        const bool near = d <= lane;
-        const bool far_ok = !near && d <= K && rowok &&
-                            (UPPER ? ((int64_t)sb * R + r + d < cd.nrows) : ((int64_t)sb * R + r - d >= 0));
-        const int dd = far_ok ? d : 0;
-        const double g = lu_get(lv, cd.row0, rl, UPPER ? rl + dd : rl - dd);
-        const double l = Ms[lane * PACK_LDM + (near ? lane - d : 0)];
-        return near ? -l : (far_ok ? (UPPER ? g * di : g) : 0.0);
+    const int nslots = 16 * NW;
+    // strip rbl = rows 16*rbl .. 16*rbl+15 of the block in STORAGE order; tile lane of strip row t: L = 16*rbl + t for the
+    // lower factor, 63 - (16*rbl + t) for the upper one (the upper tile is stored flipped).  The tiles of strip rbl+1 are
+    // requested (into registers) before strip rbl is written out, so their latency hides behind that phase.
+    d2 tv[2][16];                                              // up to 16 tiles (K = 256), two 16-byte pieces per lane each
+    auto strip_of = [&](int rbl, int &rb, int &ntf, int &cbf) {
+        rb = 4 * sb + rbl;                                     // chain-local 16-row block of the strip
+        ntf = UPPER ? KBv + rbl - 3 : KBv - rbl;               // far tiles this strip needs (may be <= 0)
+        cbf = UPPER ? 4 * sb + 4 : rb - KBv;                   // first of them (block column, chain-local)
     };
-    for (int w = 0; w < NW; ++w) {
-        d2 v[NLD];
+    auto issue_strip = [&](int rbl) {
+        int rb, ntf, cbf;
+        strip_of(rbl, rb, ntf, cbf);
+        const int rbc = rb < nblk16 ? rb : nblk16 - 1;         // clamped for addresses (rows past the chain end read as 0)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int d0 = w * 32 + 1 + 2 * i;
-            v[i].x = val(d0);
-            v[i].y = val(d0 + 1);
+        for (int ch = 0; ch < 2; ++ch) {
+            if (8 * ch >= ntf) continue;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = 8 * ch + jj < ntf ? 8 * ch + jj : ntf - 1;   // unconditional loads from clamped tiles
+                const int slot = (cbf + j) - rb + lv.KB;                     // in [0, 2 KB] by construction
+                const d2 *tp = reinterpret_cast<const d2 *>(lv.p + (((cd.row0 >> 4) + rbc) * (int64_t)lv.ntl + slot) * 256);
+                tv[ch][2 * jj] = tp[lane];
+                tv[ch][2 * jj + 1] = tp[lane + 64];
+            }
         }
+    };
+    auto store_strip = [&](int rbl) {
+        int rb, ntf, cbf;
+        strip_of(rbl, rb, ntf, cbf);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) T2[(int64_t)(w * NLD + i) * 64 + lane] = v[i];
+        for (int ch = 0; ch < 2; ++ch) {
+            if (8 * ch >= ntf) continue;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = 8 * ch + jj;
+                if (j >= ntf) continue;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int e2 = lane + 64 * hh;             // pair index inside the tile: row e2 >> 3, columns 2 (e2 & 7), +1
+                    double *dst = Fs + (e2 >> 3) * FS + 16 * j + 2 * (e2 & 7);
+                    dst[0] = tv[ch][2 * jj + hh].x; dst[1] = tv[ch][2 * jj + hh].y;
+                }
+            }
+        }
+    };
+    issue_strip(0);
+    for (int rbl = 0; rbl < 4; ++rbl) {
+        int rb, ntf, cbf;
+        strip_of(rbl, rb, ntf, cbf);
+        store_strip(rbl);
+        WAVE_LDS_FENCE();
+        if (rbl < 3) issue_strip(rbl + 1);
+        const int rin = 16 * rbl + row16;                      // row of the block (storage order)
+        const int L = UPPER ? R - 1 - rin : rin;               // its tile lane
+        const int rloc = sb * R + rin;                         // chain-local row
+        const bool rok = rin < rows_here;
+        const double dsc = UPPER ? dis[rin] : 1.0;
+        auto entry = [&](int d) -> double {
+            if (d <= L) return -Ms[L * PACK_LDM + (L - d)];
+            const bool far_ok = d <= K && rok && (UPPER ? (rloc + d < cd.nrows) : (rloc - d >= 0));
+            const int c = UPPER ? rloc + d : rloc - d;         // chain-local column
+            const int fc = far_ok ? c - 16 * cbf : 0;          // column inside the strip
+            const double g = Fs[row16 * FS + fc];
+            return far_ok ? g * dsc : 0.0;
+        };
+        for (int s0 = 0; s0 < nslots; s0 += 16) {
+            d2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int slot = s0 + 4 * u + q;
+                v[u].x = entry(2 * slot + 1);
+                v[u].y = entry(2 * slot + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) T2[(int64_t)(s0 + 4 * u + q) * 64 + L] = v[u];
+        }
+        WAVE_LDS_FENCE();                                      // the strip is overwritten by the next one
     }
 }
 
@@ -1840,14 +1906,16 @@ __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, LuView lv, int K
                                                const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
 {
     __shared__ double Ms[64 * PACK_LDM];
+    __shared__ double dis[64];
+    extern __shared__ double Fs[];   // 16 x (16 ceil(K/16) + 1): the strip of far tiles
     const int sb = blockIdx.x, p = blockIdx.y;
     const ChainDesc cd = chains[p];
     if (sb >= cd.nsteps) return;
     const GroupDesc gd = groups[p];
     const int64_t tdbl = (int64_t)NW * DPW * 64;
-    pack64_side<false>(Ms, DPW, NW, lv, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
+    pack64_side<false>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
     WAVE_LDS_FENCE();
-    pack64_side<true>(Ms, DPW, NW, lv, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
+    pack64_side<true>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
 }
 
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
@@ -1864,7 +1932,8 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
     case 64: {
         LuView lv;   // K > 32: the scratch is block-band (launch_band_to_blocks / launch_factor)
         lv.p = const_cast<double *>(lu); lv.ld = ld; lv.K = K; lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;
-        hipLaunchKernelGGL(k_pack64, grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lv, K, chains, groups, Lt, Ut, dinv);
+        hipLaunchKernelGGL(k_pack64, grid, dim3(64), (size_t)16 * (16 * ((K + 15) / 16) + 1) * sizeof(double), st, cfg.DPW, cfg.NW, lv, K,
+                           chains, groups, Lt, Ut, dinv);
         break;
     }
     default: return hipErrorInvalidValue;

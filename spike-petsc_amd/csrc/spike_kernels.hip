@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
         }
     };
     // panel of step s: registers -> LDS buffer P; the freed slots take the entering tiles
-    auto extract = [&](int s, double *P, int mode, auto fc) __attribute__((always_inline)) {   // mode 0: everything, 1: the diagonal tile only, 2: all but it
+    auto extract = [&](int s, double *P, int mode, const double (&xs)[NX], auto fc) __attribute__((always_inline)) {   // mode 0: everything, 1: the diagonal tile only, 2: all but it
         double *Pd = P, *Pc = P + TS, *Pr = P + TS + KB * TS;
         const int as = s % KB;
         // Entering tiles: block row s+KB (tiles (s+KB, s+1 .. s+KB): slots 1 .. KB of that row block, 16 KiB contiguous) and
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
                 const int e = tid + q * NTU;
                 if (e < 512) {
                     const int row = (e >> 4) & 15, col = e & 15;
-                    ((e >> 8) == 0 ? Pc : Pr)[(KB - 1) * TS + row * LDT + col] = xt[q];
+                    ((e >> 8) == 0 ? Pc : Pr)[(KB - 1) * TS + row * LDT + col] = xs[q];
                 }
             }
         }
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
     //          panel s+1 to the other buffer (freed slots refilled with the entering tiles), the write-back of step s
     // so the 16 serial pivots of step s+1 hide behind everything else of step s.
     fetch_extra(xt, 0, std::false_type{});
-    extract(0, lds, 0, std::false_type{});
+    extract(0, lds, 0, xt, std::false_type{});
     fetch_extra(xt, 1, std::false_type{});
     __syncthreads();
     if (!upd) panel_lu(0, lds, rdiag);
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
         // ---- P2(s)
         if (more && upd) {
             update(s, cur, true);
-            extract(s + 1, nxt, 1, fc);
+            extract(s + 1, nxt, 1, xt, fc);
         }
         stamp(s, 3);
         __syncthreads();
@@ -1319,7 +1319,6 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
                     }
                 }
             }
-            stamp(s, 5);
             if (more) {
                 // the two raw panel tiles of step s+2 are requested BEFORE the entering-tile loads of extract(): whatever
                 // waits for them afterwards (their copy, or their way into a spill slot) then does not wait for the eight
@@ -1327,9 +1326,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
                 double xn[NX];
                 fetch_extra(xn, s + 2, fc);
                 update(s, cur, false);
-                extract(s + 1, nxt, 2, fc);
+                stamp(s, 5);
+                // xt changes hands BEFORE extract() issues its loads: the wait for xn's load must not stand behind them
+                double xo[NX];
 #pragma unroll
-                for (int q = 0; q < NX; ++q) xt[q] = xn[q];
+                for (int q = 0; q < NX; ++q) { xo[q] = xt[q]; xt[q] = xn[q]; }
+                extract(s + 1, nxt, 2, xo, fc);
             }
         }
         stamp(s, 6);
@@ -1369,7 +1371,7 @@ static hipError_t launch_factor_mfma_la_t(const LuView &lv, const ChainDesc *cha
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(hs, stamps, sizeof hs, hipMemcpyDeviceToHost);
         (void)hipFree(stamps);
-        const char *names[7] = {"P1: panel solves", "barrier", "P2: next diag tile", "barrier", "P3: LU | write-back", "P3: upd+extract", "barrier"};
+        const char *names[7] = {"P1: panel solves", "barrier", "P2: next diag tile", "barrier", "P3: LU | wb+update", "P3: extract", "barrier"};
         for (int kind = 0; kind < 2; ++kind) {
             fprintf(stderr, "[factor stamps] %s wave, shader cycles per phase, steps 64..71:\n", kind ? "panel" : "update");
             for (int ph = 0; ph < 7; ++ph) {

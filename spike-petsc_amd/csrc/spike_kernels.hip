@@ -1508,6 +1508,194 @@ __global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(LuView lv, cons
     if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
 }
 
+// k_factor_mfma_inplace2 (round 2): the same in-place algorithm, TWO block steps per pass over the window.
+// k_factor_mfma_inplace reads and writes the whole K x K window (512 KiB per chain at K = 256: 256 chains = 128 MiB, which
+// no L2 holds) once per 16-column step: 63 us per step of which ~53 us are that pass -- the kernel moves ~8 TB/s through
+// the memory side and is bound by it, not by its 256 MFMA tiles.  Here panel s is factored as before, then only the NEXT
+// panel (block row / column s+1: 2 KB + 1 tiles) is brought up to date and factored out of a second LDS buffer, and the
+// window pass applies both rank-16 updates to a tile while it is in registers: half the passes, 8 MFMAs per tile moved.
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace2(LuView lv, const ChainDesc *chains,
+                                                                  double boost, unsigned long long *nboost)
+{
+    constexpr int NT = NW * 64;
+    constexpr int PSZ = (2 * KB + 1) * TS;
+    extern __shared__ double lds[];
+    double *PA = lds, *PB = lds + PSZ;
+    double *rdA = lds + 2 * PSZ, *rdB = rdA + 16;   // reciprocal pivots of the two panels
+    const ChainDesc cd = chains[blockIdx.x];
+    const int64_t rs = cd.row0;
+    const int np = cd.nrows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = (np + 15) / 16;
+    unsigned long long nb = 0;
+    auto ldA = [&](int rb, int cb, int row, int col) __attribute__((always_inline)) -> double {
+        const int r = 16 * rb + row, c = 16 * cb + col;
+        if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;   // identity padding past the chain end
+        return lu_get(lv, rs, r, c);
+    };
+    const int64_t rbg0 = rs >> 4;
+    auto tile_inside = [&](int rb, int cb) __attribute__((always_inline)) -> bool {
+        return 16 * (rb + 1) <= np && 16 * (cb + 1) <= np && cb - rb + lv.KB >= 0 && cb - rb + lv.KB < lv.ntl;
+    };
+    auto tile_base = [&](int rb, int cb) __attribute__((always_inline)) -> double * {
+        return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256;
+    };
+    auto load_tile = [&](double(&t)[4], int rb, int cb) __attribute__((always_inline)) {
+        if (tile_inside(rb, cb)) {
+            const double *tp = tile_base(rb, cb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
+        }
+    };
+    auto store_tile_g = [&](const double(&t)[4], int rb, int cb) __attribute__((always_inline)) {
+        if (tile_inside(rb, cb)) {
+            double *tp = tile_base(rb, cb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tp[64 * q + lane] = t[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
+                if (r < np && c < np) lu_put(lv, rs, r, c, t[q]);
+            }
+        }
+    };
+    // tile `tile` of the panel of step s held in buffer P: 0 = diagonal, 1..KB = (s+tile, s), KB+1..2KB = (s, s+tile-KB)
+    auto panel_tile = [&](double *P, int tile, int s, int &rb, int &cb) __attribute__((always_inline)) -> double * {
+        if (tile == 0) { rb = s; cb = s; return P; }
+        if (tile <= KB) { rb = s + tile; cb = s; return P + TS + (tile - 1) * TS; }
+        rb = s; cb = s + tile - KB; return P + TS + KB * TS + (tile - KB - 1) * TS;
+    };
+    auto lds_put = [&](double *T, const double(&t)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
+    };
+    // tile -= L(I) * U(J) of the panel in P (I, J in 1..KB): four MFMAs
+    auto rank16 = [&](v4d &acc, const double *P, int I, int J) __attribute__((always_inline)) {
+        const double *Lp = P + TS + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
+        const double *Up = P + TS + KB * TS + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[4 * q], Up[4 * q * LDT], acc, 0, 0, 0);
+    };
+    auto load_panel = [&](int s, double *P) __attribute__((always_inline)) {
+        for (int tile = w; tile <= 2 * KB; tile += NW) {
+            int rb, cb;
+            double *T = panel_tile(P, tile, s, rb, cb);
+            double t[4];
+            load_tile(t, rb, cb);
+            lds_put(T, t);
+        }
+    };
+    // the panel of step s+1 from the in-place values, brought up to date with the rank-16 update of panel s (in P)
+    auto next_panel = [&](int s, const double *P, double *Q) __attribute__((always_inline)) {
+        for (int tile = w; tile <= 2 * KB; tile += NW) {
+            int rb, cb;
+            double *T = panel_tile(Q, tile, s + 1, rb, cb);
+            double t[4];
+            load_tile(t, rb, cb);
+            const int I = rb - s, J = cb - s;               // >= 1; beyond KB the band of step s does not reach the tile
+            if (I <= KB && J <= KB) {
+                v4d acc = {t[0], t[1], t[2], t[3]};
+                rank16(acc, P, I, J);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = acc[q];
+            }
+            lds_put(T, t);
+        }
+    };
+    auto factor_panel = [&](int s, double *P, double *rd) __attribute__((always_inline)) {
+        __syncthreads();
+        if (w == 0) tile_lu_regs(s, P, rd, np, boost, nb, lane);
+        __syncthreads();
+        panel_solves<KB, NT>(P, P + TS, P + TS + KB * TS, rd, tid);
+        __syncthreads();
+    };
+    auto writeback = [&](int s, double *P) __attribute__((always_inline)) {
+        for (int tile = w; tile <= 2 * KB; tile += NW) {
+            int rb, cb;
+            const double *T = panel_tile(P, tile, s, rb, cb);
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = T[((lane >> 4) + 4 * q) * LDT + (lane & 15)];
+            store_tile_g(t, rb, cb);
+        }
+    };
+    // window pass: tiles (b0+I, b0+J), I, J = 1..KB, b0 = s + d (d = 1 with a second panel): -= panel s (where its band
+    // reaches) and -= panel s+1.  Software-pipelined as in k_factor_mfma_inplace: the loads of the next pair of tiles are
+    // issued before the MFMAs and stores of the current pair.
+    auto window_pass = [&](int s, const double *P, const double *Q) __attribute__((always_inline)) {
+        const int d = Q != nullptr ? 1 : 0, b0 = s + d;
+        auto tile_on = [&](int t) __attribute__((always_inline)) -> bool {
+            const int I = t / KB + 1, J = t % KB + 1;
+            return t < KB * KB && 16 * (b0 + I) < np && 16 * (b0 + J) < np;
+        };
+        auto tile_load = [&](int t, double(&a)[4]) __attribute__((always_inline)) {
+            if (tile_on(t)) load_tile(a, b0 + t / KB + 1, b0 + t % KB + 1);
+        };
+        auto tile_update_store = [&](int t, double(&a)[4]) __attribute__((always_inline)) {
+            if (!tile_on(t)) return;
+            const int I = t / KB + 1, J = t % KB + 1;
+            v4d acc = {a[0], a[1], a[2], a[3]};
+            if (I + d <= KB && J + d <= KB) rank16(acc, P, I + d, J + d);
+            if (Q != nullptr) rank16(acc, Q, I, J);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = acc[q];
+            store_tile_g(a, b0 + I, b0 + J);
+        };
+        // PD tiles per half of the pipeline: 2 x PD tiles (2 KiB each) in flight or in work per wave -- with two (as in the
+        // one-step kernel) a CU moved only ~14 GB/s each way here, the wave waiting a memory round trip per pair of tiles
+        constexpr int PD = 4;
+        double pa[PD][4], pb[PD][4];
+#pragma unroll
+        for (int u = 0; u < PD; ++u) tile_load(w + u * NW, pa[u]);
+        for (int t0 = w; t0 < KB * KB; t0 += 2 * PD * NW) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) tile_load(t0 + (PD + u) * NW, pb[u]);
+#pragma unroll
+            for (int u = 0; u < PD; ++u) tile_update_store(t0 + u * NW, pa[u]);
+#pragma unroll
+            for (int u = 0; u < PD; ++u) tile_load(t0 + (2 * PD + u) * NW, pa[u]);
+#pragma unroll
+            for (int u = 0; u < PD; ++u) tile_update_store(t0 + (PD + u) * NW, pb[u]);
+        }
+    };
+    int s = 0;
+    while (s < nblk) {
+        load_panel(s, PA);
+        factor_panel(s, PA, rdA);
+        writeback(s, PA);
+        if (s + 1 < nblk) {
+            next_panel(s, PA, PB);
+            factor_panel(s + 1, PB, rdB);
+            writeback(s + 1, PB);
+            window_pass(s, PA, PB);
+            s += 2;
+        } else {
+            window_pass(s, PA, nullptr);
+            s += 1;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
+}
+
+template <int KB, int NW>
+static hipError_t launch_factor_mfma_inplace2_t(const LuView &lv, const ChainDesc *chains, int nchains,
+                                                double boost, unsigned long long *nboost, hipStream_t st)
+{
+    const size_t shm = ((size_t)2 * (2 * KB + 1) * TS + 32) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma_inplace2<KB, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_factor_mfma_inplace2<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lv, chains, boost, nboost);
+    return hipGetLastError();
+}
+
 template <int KB, int NW>
 static hipError_t launch_factor_mfma_inplace_t(const LuView &lv, const ChainDesc *chains, int nchains,
                                                double boost, unsigned long long *nboost, hipStream_t st)
@@ -1557,7 +1745,9 @@ hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains,
     }
     if (K <= 64) return launch_factor_mfma_la_t<4, 4>(lv, chains, nchains, boost, nboost, st);
     if (K <= 128) return launch_factor_mfma_la_t<8, 8>(lv, chains, nchains, boost, nboost, st);
-    return launch_factor_mfma_inplace_t<16, 8>(lv, chains, nchains, boost, nboost, st);
+    static const bool one_step = getenv("SPIKE_FACTOR_INPLACE_1") != nullptr;   // measurement knob: one block step per window pass
+    if (one_step) return launch_factor_mfma_inplace_t<16, 8>(lv, chains, nchains, boost, nboost, st);
+    return launch_factor_mfma_inplace2_t<16, 8>(lv, chains, nchains, boost, nboost, st);
 }
 
 hipError_t launch_factor_generic(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,

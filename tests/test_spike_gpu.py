@@ -268,10 +268,12 @@ def test_full_size_properties(spike, oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("N,K,P", [(64, 0, 1), (1000, 0, 3), (64, 1, 1), (65, 3, 1), (100, 5, 1), (129, 8, 2), (200, 40, 1),
-                                   (300, 100, 1), (1000, 128, 2), (5000, 256, 3), (4097, 33, 4), (777, 17, 3)])
+                                   (300, 100, 1), (1000, 128, 2), (5000, 256, 3), (4097, 33, 4), (777, 17, 3),
+                                   (3000, 200, 2), (2103, 160, 1), (1377, 256, 1)])
 def test_edge_sizes(spike, oracle, torch_cuda, N, K, P):
     """diagonal matrices (K = 0), a single 64-row block, ragged last blocks, partitions barely longer than K,
-    unequal chain lengths (129 rows in 2 partitions: the stored-spike window must not drop the longer chain's tail)."""
+    unequal chain lengths (129 rows in 2 partitions: the stored-spike window must not drop the longer chain's tail), wide bands
+    on chains with an odd number of 16-row blocks (the two-steps-per-pass factorisation ends on a single step)."""
     band = oracle.gen_band(N, K, delta=0.9)
     f = oracle.gen_vec(N)
     sp = spike.Spike(partitions=P).setup_band(band)

@@ -2597,11 +2597,219 @@ __global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
     }
 }
 
+// ---- round 2b: the same solve without its serial core --------------------------------------------------------------------
+// k_spike_trsm spends a block step on (i) eight to sixteen factor-tile loads that the compiler leaves next to their MFMAs (a
+// memory round trip each), (ii) a 16-lane triangular substitution through LDS (120 dependent multiply-adds) that EVERY wave
+// of a chain side repeats with the same diagonal tile: 9 us per step at K = 128.  Here the diagonal tiles of the region are
+// inverted once per chain side (k_trsm_diag_inv: one wave per tile, lanes 0-15 a column of L^-1, lanes 16-31 a column of
+// U^-1), so the triangular solve of a step is one more 16 x 16 x 16 product, and the A operands of step rb+1 (off-diagonal
+// tiles, inverse tile, Z tile) are requested into registers before the MFMAs of step rb: no LDS, one exposed chain of
+// 4 (KB + 1) dependent MFMAs per step.  The pack kernel treats the 64 x 64 diagonal blocks of the sweeps the same way.
+__global__ __launch_bounds__(64) void k_trsm_diag_inv(TrsmArgs a, double *inv)
+{
+    __shared__ double T[16 * 17];
+    const int lane = threadIdx.x;
+    const int p = blockIdx.y, side = blockIdx.z;
+    const ChainDesc cd = a.chains[p];
+    const int np = cd.nrows;
+    const int region = a.region < np ? a.region : np;
+    const int NB = region / 16;
+    const int rb = blockIdx.x;
+    if (rb >= NB) return;
+    const int rb0 = side == 0 ? 0 : (np - region) / 16;
+    const double *tp = a.lv.p + (((cd.row0 >> 4) + rb0 + rb) * (int64_t)a.lv.ntl + a.lv.KB) * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * 17 + (lane & 15)] = tp[64 * q + lane];
+    WAVE_LDS_FENCE();
+    const int NBmax = a.region / 16;
+    double *out = inv + ((((int64_t)p * 2 + side) * NBmax + rb) * 2) * 256;   // [L^-1 | U^-1], row-major 16 x 16 each
+    const int j = lane & 15;
+    double x[16];
+    if (lane < 16) {                     // column j of L^-1 (L unit lower: the stored strict lower triangle of the tile)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) v = fma(-T[i * 17 + k], x[k], v);
+            x[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i * 16 + j] = x[i];
+    } else if (lane < 32) {              // column j of U^-1 (upper triangle with its diagonal)
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = i + 1; k < 16; ++k) v = fma(-T[i * 17 + k], x[k], v);
+            x[i] = v / T[i * 17 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[256 + i * 16 + j] = x[i];
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a, const double *inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int wg = w + nwv * blockIdx.z;         // column tile of this wave
+    const int ncw = nwv * gridDim.z;
+    const int p = blockIdx.x, side = blockIdx.y;
+    const ChainDesc cd = a.chains[p];
+    const int K = a.K, m = a.m;
+    const int np = cd.nrows;
+    const bool on = side == 0 ? (a.grow0 + cd.row0 > 0) : (a.grow0 + cd.row0 + np < a.n_global);
+    const int c0 = 16 * wg;
+    double *tips = (side == 0 ? a.Wt : a.Vb) + (int64_t)p * K * K;
+    if (!on) return;                             // no neighbour on this side: the tips stay zero (setup cleared them)
+    const int region = a.region < np ? a.region : np;
+    const int NB = region / 16;
+    const int rb0 = side == 0 ? 0 : (np - region) / 16;
+    const int rbs = side == 0 ? 0 : (np - K) / 16 - rb0;
+    const int64_t rbg0 = (cd.row0 >> 4) + rb0;
+    const LuView lv = a.lv;
+    double *zs = a.zscratch + (((int64_t)p * 2 + side) * ncw + wg) * (int64_t)NB * 256;
+    const double *invp = inv + (((int64_t)p * 2 + side) * (a.region / 16)) * 512;
+    const int li = lane & 15, lk = lane >> 4;
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    // ROW PERMUTATION.  The MFMA layouts are fixed: A operand lane (i = li, k = lk + 4q), C/D element r of lane = row lk + 4r.
+    // Fed with the rows of a factor tile in natural order, the A operand of slice q is tile[li][lk + 4q]: four 8-byte loads
+    // per tile, each touching all sixteen 128-byte lines of the tile for 32 bytes -- the step was bound by line requests to
+    // the L1, not by memory or MFMA (K = 128: ~8 us per step whatever else changed).  With the block's rows taken in the
+    // order pi(i') = 4 (i' mod 4) + i' / 4 -- consistently: A'[i'][k'] = tile[pi(i')][pi(k')], and every solved tile lives
+    // in registers as X[pi(.)][.] -- the products are unchanged (pi is a bijection of the contraction index), element r of
+    // a solved tile is row 4 lk + r, and the A operand of a lane is tile[pi(li)][4 lk .. 4 lk + 3]: ONE 32-byte load per
+    // tile and lane, every line read once.
+    const int pli = 4 * (li & 3) + (li >> 2);
+
+    v4 Xw[KB];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
+
+    auto rhs_tile = [&](int rb) __attribute__((always_inline)) -> v4 {
+        v4 t = {0.0, 0.0, 0.0, 0.0};
+        const int col = c0 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (rb0 + rb) * 16 + 4 * lk + r;       // chain-local row (permuted layout: element r = row 4 lk + r)
+            double v = 0.0;
+            if (col < K) {
+                if (side == 0) {
+                    if (row < K && row <= col) v = a.band[(int64_t)(col - row) * a.ld + cd.row0 + row];
+                } else {
+                    const int aa = row - (np - K);
+                    if (aa >= 0 && col <= aa) v = a.band[(int64_t)(2 * K + col - aa) * a.ld + cd.row0 + row];
+                }
+            }
+            t[r] = v;
+        }
+        return t;
+    };
+    // A operands of one block step: the KB off-diagonal factor tiles, the inverse of the diagonal tile, (backward) the Z tile
+    struct StepOps { v4 A[KB]; v4 I; v4 Z; };
+    auto fetch = [&](StepOps &o, int rb, bool bwd) __attribute__((always_inline)) {
+        const int rbc = rb < 0 ? 0 : (rb >= NB ? NB - 1 : rb);  // clamped: a step past the range fetches a valid block, unused
+        const double *rowp = lv.p + ((rbg0 + rbc) * lv.ntl) * 256 + pli * 16 + 4 * lk;
+#pragma unroll
+        for (int d = 1; d <= KB; ++d)
+            o.A[d - 1] = *reinterpret_cast<const v4 *>(rowp + (int64_t)(bwd ? lv.KB + d : lv.KB - d) * 256);
+        o.I = *reinterpret_cast<const v4 *>(invp + (int64_t)rbc * 512 + (bwd ? 256 : 0) + pli * 16 + 4 * lk);
+        if (bwd) o.Z = *reinterpret_cast<const v4 *>(zs + (int64_t)rbc * 256 + 4 * lane);
+    };
+    auto solve_diag = [&](const v4 &I, const v4 &B) __attribute__((always_inline)) -> v4 {
+        v4 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(I[q], B[q], r, 0, 0, 0);
+        return r;
+    };
+
+    // ---------------- forward: Z ----------------
+    StepOps cur, nxt;
+    const int fstart = rbs - rbs % KB;
+    fetch(nxt, rbs, false);
+    for (int rbb = fstart; rbb < NB; rbb += KB) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int rb = rbb + u;
+            if (rb < rbs || rb >= NB) continue;
+            cur = nxt;
+            fetch(nxt, rb + 1, false);
+            v4 acc = rhs_tile(rb);
+#pragma unroll
+            for (int d = 1; d <= KB; ++d)
+                if (rb - d >= rbs) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur.A[d - 1][q], Xw[(u - d + KB) % KB][q], acc, 0, 0, 0);
+                }
+            const v4 Z = solve_diag(cur.I, acc);
+            Xw[u] = Z;
+            *reinterpret_cast<v4 *>(zs + (int64_t)rb * 256 + 4 * lane) = Z;   // the wave's own scratch: 32 bytes per lane
+        }
+    }
+    // ---------------- backward: X ----------------
+#pragma unroll
+    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
+    double mi = 0.0, mo = 0.0;
+    double *spike = (side == 0 ? a.Wf : a.Vf);
+    // the Z tiles this wave wrote are read back by the same lanes: program order within the wave; the loads below are issued
+    // after the stores above, no other wave touches them
+    fetch(nxt, NB - 1, true);
+    for (int rbb = ((NB - 1) / KB) * KB; rbb >= 0; rbb -= KB) {
+#pragma unroll
+        for (int u = KB - 1; u >= 0; --u) {
+            const int rb = rbb + u;
+            if (rb >= NB) continue;
+            cur = nxt;
+            fetch(nxt, rb - 1, true);
+            v4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (rb >= rbs) acc = cur.Z;
+#pragma unroll
+            for (int d = 1; d <= KB; ++d)
+                if (rb + d < NB) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur.A[d - 1][q], Xw[(u + d) % KB][q], acc, 0, 0, 0);
+                }
+            const v4 X = solve_diag(cur.I, acc);
+            Xw[u] = X;
+            // ---- outputs: element r of lane = (row 4 lk + r of the block, column li)
+            const int col = c0 + li;
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (rb0 + rb) * 16 + 4 * lk + r;    // chain-local row
+                    const double v = X[r];
+                    const int dist = side == 0 ? row : np - 1 - row; // rows from the interface
+                    if (dist < K) tips[(int64_t)(side == 0 ? row : row - (np - K)) * K + col] = v;
+                    if (spike != nullptr && dist < m) {
+                        spike[((int64_t)p * K + col) * m + (side == 0 ? row : row - (np - m))] = v;
+                        mi = fmax(mi, fabs(v));
+                        if (dist >= m - 32) mo = fmax(mo, fabs(v));
+                    }
+                }
+            }
+        }
+    }
+    if (spike != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
+        if (lane == 0) {
+            if (mi > __hip_atomic_load(a.absmax_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_in, mi);
+            if (mo > __hip_atomic_load(a.absmax_edge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_edge, mo);
+        }
+    }
+}
+
 // doubles of Z scratch launch_spike_trsm needs
 size_t spike_trsm_scratch_doubles(int K, int nchains, int region)
 {
     const int nz = K > 128 ? 2 : 1, nwv = ((K + nz - 1) / nz + 15) / 16;
-    return (size_t)nchains * 2 * (size_t)(nwv * nz) * (size_t)(region / 16) * 256;
+    const int nz4 = K > 128 ? 4 : 1, nwv4 = ((K + nz4 - 1) / nz4 + 15) / 16;            // k_spike_trsm2 deals a wide chain side to four workgroups
+    const int waves = nwv * nz > nwv4 * nz4 ? nwv * nz : nwv4 * nz4;
+    return (size_t)nchains * 2 * (size_t)waves * (size_t)(region / 16) * 256           // Z tiles per (chain, side, wave)
+           + (size_t)nchains * 2 * (size_t)(region / 16) * 512;                        // inverted diagonal tiles [L^-1 | U^-1]
 }
 
 hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
@@ -2616,6 +2824,19 @@ hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDe
     a.absmax_in = absmax_in; a.absmax_edge = absmax_edge;
     const int nz = K > 128 ? 2 : 1;                       // K > 128: the columns of a chain side over two workgroups
     const int nwv = ((K + nz - 1) / nz + 15) / 16;        // waves per workgroup (<= 8): 16 columns each
+    static const bool old_trsm = getenv("SPIKE_TRSM_OLD") != nullptr;   // measurement knob: substitution through LDS, no prefetch
+    if (!old_trsm) {
+        // K > 128: four workgroups of four waves per chain side (one wave per SIMD: the operands of two steps and the window of
+        // 16 solved tiles need ~420 registers)
+        const int nz4 = K > 128 ? 4 : 1, nwv4 = ((K + nz4 - 1) / nz4 + 15) / 16;
+        const int waves = nwv * nz > nwv4 * nz4 ? nwv * nz : nwv4 * nz4;
+        double *inv = zscratch + (size_t)nchains * 2 * (size_t)waves * (size_t)(region / 16) * 256;
+        hipLaunchKernelGGL(k_trsm_diag_inv, dim3(region / 16, nchains, 2), dim3(64), 0, st, a, inv);
+        if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm2<4>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
+        else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm2<8>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
+        else hipLaunchKernelGGL(k_spike_trsm2<16>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
+        return hipGetLastError();
+    }
     const size_t shm = (size_t)nwv * 2 * 16 * 17 * sizeof(double);
     if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm<4>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
     else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm<8>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);

@@ -170,6 +170,8 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
+    double *dTips1 = nullptr;                             // K = 1: saved chain-end values of the swept vector (2 P doubles)
+    int nif_local_all = 0;                                // interfaces between this rank's chains
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
     // (the 26 KiB of interface descriptors at 256 chains is) makes the FIRST such copy of a process build the runtime's
@@ -322,7 +324,7 @@ static void free_factors(spike_handle h)
     h->ownA = false;
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
-    F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
+    F(h->dTips1); F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
     F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
     for (int i = 0; i < 2; ++i) if (h->hostDots[i]) { (void)hipHostFree(h->hostDots[i]); h->hostDots[i] = nullptr; }
@@ -1143,6 +1145,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(upload(h, h->dIfsInt, ii.data(), sizeof(IfaceDesc) * ii.size(), st));
             HIPCHK(hipStreamSynchronize(st));
         }
+        h->nif_local_all = nif_local;
+        if (h->spike_m > 0 && cfg.scan && !multi) HIPCHK(dalloc(&h->dTips1, (size_t)2 * P));   // k_couple_k1
         if (h->spike_m > 0) {
             // one-pass variant: the interface kernel only has to deliver the tip solutions
             HIPCHK(dalloc(&h->dXb, (size_t)(P + 2) * K));
@@ -1236,6 +1240,11 @@ static int apply_dev(spike_handle h, const double *x, double *y)
             HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
         }
     }
+    // K = 1, one rank, every interface coupled, windows that do not overlap: the scalar coupling step (two tiny launches)
+    if (h->cfg.scan && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
+        h->nif_local_all == P - 1)
+        return launch_couple_k1(P, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
+                   ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_k1 launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes

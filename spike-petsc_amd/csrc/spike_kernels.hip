@@ -3236,6 +3236,55 @@ hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchai
 }
 
 // ------------------------------------------------------------------------------------------
+// K = 1 (tridiagonal), one rank, coupled, stored spikes: the whole coupling step in two tiny launches.  The general path
+// (k_iface_apply with one workgroup per interface and three barrier-separated 1 x 1 "mat-vecs", then k_spike_correct with a
+// 256-thread workgroup per chain end for ~64 rows) costs ~30 us for a few MB at 8192 chains -- a fifth of a K = 1 apply.
+// k_tips_k1 saves the chain-end values of the swept vector (the corrections below overwrite them), k_couple_k1 has every
+// chain solve its two 1 x 1 interface systems itself (four scalars from the saved tips, three from the interface arrays)
+// and correct its first and last m rows.  Same operations in the same order as the general path (no contraction).
+// ------------------------------------------------------------------------------------------
+__global__ void k_tips_k1(int nchains, const ChainDesc *chains, const double *y, double *tipT, double *tipB)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nchains) return;
+    const ChainDesc cd = chains[p];
+    tipT[p] = y[cd.row0];
+    tipB[p] = y[cd.row0 + cd.nrows - 1];
+}
+
+__global__ __launch_bounds__(64) void k_couple_k1(int nchains, int m, const ChainDesc *chains, const double *tipT, const double *tipB,
+                                                  const double *WT, const double *ST, const double *VT, const double *Wf,
+                                                  const double *Vf, double *y)
+{
+#pragma clang fp contract(off)
+    const int p = blockIdx.x;
+    const ChainDesc cd = chains[p];
+    double xb_prev = 0.0, xt_next = 0.0;
+    if (p > 0) {                       // interface p-1 | p: x_t = S^-1 (g_t - W g_b), x_b = g_b - V x_t; the top of p takes x_b
+        const double gb = tipB[p - 1], gt = tipT[p];
+        const double xt = ST[p - 1] * (gt - WT[p - 1] * gb);
+        xb_prev = gb - VT[p - 1] * xt;
+    }
+    if (p + 1 < nchains) {             // interface p | p+1: the bottom of p takes x_t
+        const double gb = tipB[p], gt = tipT[p + 1];
+        xt_next = ST[p] * (gt - WT[p] * gb);
+    }
+    for (int r = threadIdx.x; r < m; r += 64) {
+        if (p > 0) y[cd.row0 + r] -= Wf[(int64_t)p * m + r] * xb_prev;
+        if (p + 1 < nchains) y[cd.row0 + cd.nrows - m + r] -= Vf[(int64_t)p * m + r] * xt_next;
+    }
+}
+
+hipError_t launch_couple_k1(int nchains, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
+                            const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tips_k1, dim3((nchains + 255) / 256), dim3(256), 0, st, nchains, chains, y, tips, tips + nchains);
+    hipLaunchKernelGGL(k_couple_k1, dim3(nchains), dim3(64), 0, st, nchains, m, chains, tips, tips + nchains, WT, ST, VT, Wf, Vf, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // read-bandwidth ceiling: the same access shape as a sweep's tile stream (16 B per lane, 1 KiB per wave
 // instruction, non-temporal, every byte read once) with nothing else in the way.  bench.py reports it beside
 // the spec peak so that roofline.frac can be read against what this chip delivers for a pure read stream.

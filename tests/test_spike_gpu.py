@@ -63,6 +63,23 @@ def test_apply_matches_oracle(spike, oracle, torch_cuda, N, K, P, delta):
         sp.close()
 
 
+@pytest.mark.parametrize("N,P", [(2 ** 18, 0), (2 ** 16 + 77, 64), (4096, 16)])
+def test_tridiagonal_scalar_coupling_step(spike, oracle, torch_cuda, N, P):
+    """K = 1, one rank, coupled, stored spikes: the coupling step is k_tips_k1 + k_couple_k1 (every chain solves its two
+    1 x 1 interface systems itself) instead of k_iface_apply + k_spike_correct.  Same preconditioner: equal to the oracle
+    with the same partitions, and (dominant system) to the exact solve."""
+    band = oracle.gen_band(N, 1, delta=1.2)
+    f = oracle.gen_vec(N)
+    sp = spike.Spike(partitions=P, variant="coupled").setup_band(band)
+    i = sp.info()
+    assert i.passes == 1 and 0 < 2 * i.spike_rows <= N // i.chains_local     # the scalar path's precondition
+    x = sp.apply(f)
+    assert _rel(x, oracle.Spike(band, i.P_local).apply(f, 1)) <= TOL
+    assert _rel(x, oracle.Spike(band, 1).apply(f, 0)) <= 1e-10
+    x2 = sp.apply(f)                                                            # repeated: the saved tips are rewritten each time
+    assert np.array_equal(x, x2)
+
+
 @pytest.mark.parametrize("N,K,P", [(16384, 8, 8), (65536, 32, 16), (65536, 64, 8), (2 ** 17, 128, 8)])
 def test_coupled_one_pass_and_two_pass_agree(spike, oracle, torch_cuda, N, K, P):
     """The coupled variant keeps the decayed part of the spikes when they are short and then needs ONE pass over the

@@ -170,8 +170,9 @@ struct spike_handle_s {
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
-    double *dTips1 = nullptr;                             // K = 1: saved chain-end values of the swept vector (2 P doubles)
+    double *dTips1 = nullptr;                             // K <= 8: saved chain-end values of the swept vector (2 P K doubles)
     int nif_local_all = 0;                                // interfaces between this rank's chains
+    int small_kmax = 1;                                   // k_couple_small for K <= this (measured: pays at K = 1 only; option small_coupling_kmax)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
     // (the 26 KiB of interface descriptors at 256 chains is) makes the FIRST such copy of a process build the runtime's
@@ -415,6 +416,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
         if (v == "refine_never" || v == "never") h->cgs_refine = 0;
         else if (v == "refine_ifneeded" || v == "ifneeded") h->cgs_refine = 1;
@@ -1146,7 +1148,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(hipStreamSynchronize(st));
         }
         h->nif_local_all = nif_local;
-        if (h->spike_m > 0 && cfg.scan && !multi) HIPCHK(dalloc(&h->dTips1, (size_t)2 * P));   // k_couple_k1
+        if (h->spike_m > 0 && K >= 1 && K <= 8 && !multi) HIPCHK(dalloc(&h->dTips1, (size_t)2 * P * K));   // k_couple_small
         if (h->spike_m > 0) {
             // one-pass variant: the interface kernel only has to deliver the tip solutions
             HIPCHK(dalloc(&h->dXb, (size_t)(P + 2) * K));
@@ -1240,11 +1242,13 @@ static int apply_dev(spike_handle h, const double *x, double *y)
             HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
         }
     }
-    // K = 1, one rank, every interface coupled, windows that do not overlap: the scalar coupling step (two tiny launches)
-    if (h->cfg.scan && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
+    // K = 1 (option small_coupling_kmax: up to 8 -- measured 2026-10: K = 2..8 gain nothing, their chains carry 200-row spike
+    // windows and the general kernels are as fast), one rank, every interface coupled, windows that do not overlap: the small
+    // coupling step (two tiny launches)
+    if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
         h->nif_local_all == P - 1)
-        return launch_couple_k1(P, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
-                   ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_k1 launch failed");
+        return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
+                   ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes

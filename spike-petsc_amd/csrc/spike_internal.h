@@ -122,8 +122,8 @@ hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc 
                                int64_t ldr = 0);
 hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
                                int *extent, hipStream_t st);
-hipError_t launch_couple_k1(int nchains, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
-                            const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st);
+hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
+                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st);
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0);
 

@@ -3236,51 +3236,78 @@ hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchai
 }
 
 // ------------------------------------------------------------------------------------------
-// K = 1 (tridiagonal), one rank, coupled, stored spikes: the whole coupling step in two tiny launches.  The general path
-// (k_iface_apply with one workgroup per interface and three barrier-separated 1 x 1 "mat-vecs", then k_spike_correct with a
-// 256-thread workgroup per chain end for ~64 rows) costs ~30 us for a few MB at 8192 chains -- a fifth of a K = 1 apply.
-// k_tips_k1 saves the chain-end values of the swept vector (the corrections below overwrite them), k_couple_k1 has every
-// chain solve its two 1 x 1 interface systems itself (four scalars from the saved tips, three from the interface arrays)
-// and correct its first and last m rows.  Same operations in the same order as the general path (no contraction).
+// Narrow bands (K <= 8), one rank, coupled, stored spikes: the whole coupling step in two small launches.  The general path
+// (k_iface_apply: one workgroup per interface, three barrier-separated K x K mat-vecs; then k_spike_correct: a 256-thread
+// workgroup per chain end for its ~64-200 rows) costs 30-60 us for a few MB at 8192-16384 chains -- a fifth of a K = 1
+// apply.  k_tips_small saves the K values at both ends of every chain of the swept vector (the corrections below overwrite
+// them), k_couple_small has every chain solve its two interface systems itself and correct its first and last m rows.
 // ------------------------------------------------------------------------------------------
-__global__ void k_tips_k1(int nchains, const ChainDesc *chains, const double *y, double *tipT, double *tipB)
+__global__ void k_tips_small(int nchains, int K, const ChainDesc *chains, const double *y, double *tipT, double *tipB)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nchains) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchains * K) return;
+    const int p = t / K, a = t % K;
     const ChainDesc cd = chains[p];
-    tipT[p] = y[cd.row0];
-    tipB[p] = y[cd.row0 + cd.nrows - 1];
+    tipT[t] = y[cd.row0 + a];
+    tipB[t] = y[cd.row0 + cd.nrows - K + a];
 }
 
-__global__ __launch_bounds__(64) void k_couple_k1(int nchains, int m, const ChainDesc *chains, const double *tipT, const double *tipB,
-                                                  const double *WT, const double *ST, const double *VT, const double *Wf,
-                                                  const double *Vf, double *y)
+__global__ __launch_bounds__(64) void k_couple_small(int nchains, int K, int m, const ChainDesc *chains, const double *tipT,
+                                                     const double *tipB, const double *WT, const double *ST, const double *VT,
+                                                     const double *Wf, const double *Vf, double *y)
 {
 #pragma clang fp contract(off)
-    const int p = blockIdx.x;
+    __shared__ double gb[8], gt[8], v1[8], xt[8], xbp[8], xtn[8];
+    const int p = blockIdx.x, a = threadIdx.x;
     const ChainDesc cd = chains[p];
-    double xb_prev = 0.0, xt_next = 0.0;
-    if (p > 0) {                       // interface p-1 | p: x_t = S^-1 (g_t - W g_b), x_b = g_b - V x_t; the top of p takes x_b
-        const double gb = tipB[p - 1], gt = tipT[p];
-        const double xt = ST[p - 1] * (gt - WT[p - 1] * gb);
-        xb_prev = gb - VT[p - 1] * xt;
+    const int kk = K * K;
+    // interface i (between chains i and i+1): x_t = S^-1 (g_t - W g_b), x_b = g_b - V x_t; matrices stored transposed
+    for (int half = 0; half < 2; ++half) {
+        const int i = half == 0 ? p - 1 : p;
+        if (i < 0 || i + 1 >= nchains) { if (a < K) (half == 0 ? xbp : xtn)[a] = 0.0; __syncthreads(); continue; }
+        if (a < K) { gb[a] = tipB[(int64_t)i * K + a]; gt[a] = tipT[(int64_t)(i + 1) * K + a]; }
+        __syncthreads();
+        if (a < K) {
+            double s = 0.0;
+            for (int c = 0; c < K; ++c) s += WT[(int64_t)i * kk + c * K + a] * gb[c];
+            v1[a] = gt[a] - s;
+        }
+        __syncthreads();
+        if (a < K) {
+            double s = 0.0;
+            for (int c = 0; c < K; ++c) s += ST[(int64_t)i * kk + c * K + a] * v1[c];
+            xt[a] = s;
+            if (half == 1) xtn[a] = s;           // the bottom of chain p takes x_t of the interface below it
+        }
+        __syncthreads();
+        if (half == 0 && a < K) {                // the top of chain p takes x_b of the interface above it
+            double s = 0.0;
+            for (int c = 0; c < K; ++c) s += VT[(int64_t)i * kk + c * K + a] * xt[c];
+            xbp[a] = gb[a] - s;
+        }
+        __syncthreads();
     }
-    if (p + 1 < nchains) {             // interface p | p+1: the bottom of p takes x_t
-        const double gb = tipB[p], gt = tipT[p + 1];
-        xt_next = ST[p] * (gt - WT[p] * gb);
-    }
-    for (int r = threadIdx.x; r < m; r += 64) {
-        if (p > 0) y[cd.row0 + r] -= Wf[(int64_t)p * m + r] * xb_prev;
-        if (p + 1 < nchains) y[cd.row0 + cd.nrows - m + r] -= Vf[(int64_t)p * m + r] * xt_next;
+    for (int r = a; r < m; r += 64) {
+        if (p > 0) {
+            double s = 0.0;
+            for (int c = 0; c < K; ++c) s += Wf[((int64_t)p * K + c) * m + r] * xbp[c];
+            y[cd.row0 + r] -= s;
+        }
+        if (p + 1 < nchains) {
+            double s = 0.0;
+            for (int c = 0; c < K; ++c) s += Vf[((int64_t)p * K + c) * m + r] * xtn[c];
+            y[cd.row0 + cd.nrows - m + r] -= s;
+        }
     }
 }
 
-hipError_t launch_couple_k1(int nchains, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
-                            const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st)
+hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
+                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st)
 {
-    if (nchains <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tips_k1, dim3((nchains + 255) / 256), dim3(256), 0, st, nchains, chains, y, tips, tips + nchains);
-    hipLaunchKernelGGL(k_couple_k1, dim3(nchains), dim3(64), 0, st, nchains, m, chains, tips, tips + nchains, WT, ST, VT, Wf, Vf, y);
+    if (nchains <= 0 || K < 1 || K > 8) return hipErrorInvalidValue;
+    double *tipT = tips, *tipB = tips + (size_t)nchains * K;
+    hipLaunchKernelGGL(k_tips_small, dim3((nchains * K + 255) / 256), dim3(256), 0, st, nchains, K, chains, y, tipT, tipB);
+    hipLaunchKernelGGL(k_couple_small, dim3(nchains), dim3(64), 0, st, nchains, K, m, chains, tipT, tipB, WT, ST, VT, Wf, Vf, y);
     return hipGetLastError();
 }
 

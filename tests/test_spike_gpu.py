@@ -63,18 +63,24 @@ def test_apply_matches_oracle(spike, oracle, torch_cuda, N, K, P, delta):
         sp.close()
 
 
-@pytest.mark.parametrize("N,P", [(2 ** 18, 0), (2 ** 16 + 77, 64), (4096, 16)])
-def test_tridiagonal_scalar_coupling_step(spike, oracle, torch_cuda, N, P):
-    """K = 1, one rank, coupled, stored spikes: the coupling step is k_tips_k1 + k_couple_k1 (every chain solves its two
-    1 x 1 interface systems itself) instead of k_iface_apply + k_spike_correct.  Same preconditioner: equal to the oracle
-    with the same partitions, and (dominant system) to the exact solve."""
-    band = oracle.gen_band(N, 1, delta=1.2)
+@pytest.mark.parametrize("N,K,P", [(2 ** 18, 1, 0), (2 ** 16 + 77, 1, 64), (4096, 1, 16), (2 ** 18, 2, 0), (2 ** 16, 3, 32),
+                                   (2 ** 17, 4, 0), (2 ** 17 + 33, 8, 0), (2 ** 16, 5, 16)])
+def test_narrow_band_coupling_step(spike, oracle, torch_cuda, N, K, P):
+    """K <= 8, one rank, coupled, stored spikes: the coupling step can be k_tips_small + k_couple_small (every chain solves its
+    two K x K interface systems itself) instead of k_iface_apply + k_spike_correct (default for K = 1).  Same preconditioner: equal to the
+    oracle with the same partitions, and (dominant system) to the exact solve."""
+    band = oracle.gen_band(N, K, delta=1.2)
     f = oracle.gen_vec(N)
-    sp = spike.Spike(partitions=P, variant="coupled").setup_band(band)
+    sp = spike.Spike(partitions=P, variant="coupled")
+    sp.set_option("small_coupling_kmax", 8)        # default 1: the path pays at K = 1 only, the kernel serves K <= 8
+    sp.setup_band(band)
     i = sp.info()
-    assert i.passes == 1 and 0 < 2 * i.spike_rows <= N // i.chains_local     # the scalar path's precondition
+    assert i.passes == 1 and 0 < 2 * i.spike_rows <= (N // i.chains_local) // 64 * 64     # the small path's precondition
     x = sp.apply(f)
-    assert _rel(x, oracle.Spike(band, i.P_local).apply(f, 1)) <= TOL
+    if P:
+        assert _rel(x, oracle.Spike(band, P).apply(f, 1)) <= 1e-10      # sub-chains reproduce the P-partition preconditioner to rounding
+    else:
+        assert _rel(x, oracle.Spike(band, i.P_local).apply(f, 1)) <= TOL
     assert _rel(x, oracle.Spike(band, 1).apply(f, 0)) <= 1e-10
     x2 = sp.apply(f)                                                            # repeated: the saved tips are rewritten each time
     assert np.array_equal(x, x2)

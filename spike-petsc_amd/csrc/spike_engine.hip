@@ -500,6 +500,10 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // 0.172-0.181 ms per apply (half the CUs idle), 512 chains 0.138, 1024 chains 0.162 (twice the spike traffic)
     if (cfg.R == 32) minrows = (int64_t)64 * K;
     if (minrows < 512) minrows = 512;
+    // K = 2..4 (16 chains per wave): the stored spikes of a dominant system still reach ~190 rows, so 512-row chains spend
+    // three quarters of their rows in correction windows.  Measured at N = 8M (ms per apply; 16384 / 8192 / 4096 chains):
+    // K = 2: 0.230 / 0.188 / 0.274, K = 4: 0.247 / 0.194 / 0.275
+    if (cfg.R == 4 && minrows < 1024) minrows = 1024;
     // Short systems (strong scaling: N/G rows per GPU) with one chain per workgroup: 32 K rows per chain would leave CUs
     // without a chain, and ~128 busy CUs are the least that saturate HBM (tools/cu_bw_probe.hip).  A chain may then be as
     // short as two spike windows of a dominant system (2 x 11 K rows) plus a block -- the windows must not overlap.

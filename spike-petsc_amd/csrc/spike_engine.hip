@@ -500,10 +500,6 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // 0.172-0.181 ms per apply (half the CUs idle), 512 chains 0.138, 1024 chains 0.162 (twice the spike traffic)
     if (cfg.R == 32) minrows = (int64_t)64 * K;
     if (minrows < 512) minrows = 512;
-    // K = 2..4 (16 chains per wave): the stored spikes of a dominant system still reach ~190 rows, so 512-row chains spend
-    // three quarters of their rows in correction windows.  Measured at N = 8M (ms per apply; 16384 / 8192 / 4096 chains):
-    // K = 2: 0.230 / 0.188 / 0.274, K = 4: 0.247 / 0.194 / 0.275
-    if (cfg.R == 4 && minrows < 1024) minrows = 1024;
     // Short systems (strong scaling: N/G rows per GPU) with one chain per workgroup: 32 K rows per chain would leave CUs
     // without a chain, and ~128 busy CUs are the least that saturate HBM (tools/cu_bw_probe.hip).  A chain may then be as
     // short as two spike windows of a dominant system (2 x 11 K rows) plus a block -- the windows must not overlap.
@@ -522,7 +518,18 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // K=128 2.280/1.496/1.646, K=192 3.210/2.413/-, K=256 3.975/3.069/-.
     const int64_t ncu = ncu_dev;
     int64_t target = ncu * ((4 + cfg.NW - 1) / cfg.NW) * cfg.CPW();
+    // One-wave workgroups that carry several chains (K <= 32): round 2b measured at N = 8M (ms per apply; chains):
+    //   K = 4 : 16384: 0.247   8192: 0.194   4096: 0.275        K = 8 : 8192: 0.315   4096: 0.262   2048: 0.291
+    //   K = 16:  4096: 0.496   2048: 0.442   1024: 0.475        K = 32: 2048: 0.860   1024: 0.811    512: 0.795
+    // i.e. two waves per CU (one for K in (16, 32], whose chain pairs may be dealt to four waves at launch time): half the
+    // chains of the four-waves rule, and every chain twice as long against the same spike windows.
+    if (cfg.NW == 1 && cfg.CPW() > 1) target = ncu * (cfg.R == 32 ? 1 : 2) * cfg.CPW();
     if (cfg.scan) target = 8192;  // one light wave per chain: 32 waves per CU keep enough loads in flight
+    // K = 2..4 (16 chains per wave): the stored spikes of a dominant system still reach ~190 rows, so 512-row chains spend
+    // three quarters of their rows in correction windows -- 1024-row chains where that still leaves two waves per CU
+    // (N = 8M: K = 2 0.230 -> 0.189 ms, K = 4 0.247 -> 0.195), the wave count first where it does not (N = 4M, K = 4:
+    // 8192 chains of 512 rows 0.122 ms, 4096 of 1024 rows 0.152)
+    if (cfg.R == 4 && minrows < 1024 && n / 1024 >= target) minrows = 1024;
     int64_t byrows = n / minrows;
     int64_t P = target < byrows ? target : byrows;
     if (P > nblk) P = nblk;

@@ -66,7 +66,9 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(256, N) == 256          # 8 waves per chain
     assert L.spike_auto_partitions(64, N) == 512           # 2 waves per chain -> 2 workgroups per CU
     assert L.spike_auto_partitions(96, N) == 512
-    assert L.spike_auto_partitions(32, N) == 2048          # 2 chains per wave, 1024 one-wave workgroups
+    assert L.spike_auto_partitions(32, N) == 512           # 2 chains per wave: one workgroup per CU (measured: fewer, longer chains win for K <= 32)
+    assert L.spike_auto_partitions(8, 2 * N) == 4096       # 8 chains per wave, two waves per CU
+    assert L.spike_auto_partitions(4, 2 * N) == 8192       # 16 chains per wave, two waves per CU, >= 1024 rows per chain
     assert L.spike_auto_partitions(1, 2 ** 24) == 8192     # scan path
     assert L.spike_auto_partitions(128, 32768) == 11       # short systems: a chain may be as short as two spike windows + a block
     assert L.spike_auto_partitions(128, 524288) == 182     # N/8 rows per GPU of the headline: 182 chains of 2880 rows, not 128 of 4096

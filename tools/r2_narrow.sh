@@ -1,10 +1,7 @@
 #!/bin/bash
-set -e
+# narrow and medium bands with auto partitions: N = 8M and N = 4M, K = 2..64 (+ BASELINE config 2)
 mkdir -p gpurun_out/r2
-B="python bench.py --no-cpu --no-ksp --steps 50 --warmup 5"
-$B --n 1048576 --k 32 --partitions 64 > gpurun_out/r2/nb_c2.json 2> gpurun_out/r2/nb_err.txt
-for k in 2 3 4 8 16; do
-  $B --n 8388608 --k $k > gpurun_out/r2/nb_k$k.json 2>> gpurun_out/r2/nb_err.txt
-done
-$B --n 16777216 --k 1 > gpurun_out/r2/nb_k1.json 2>> gpurun_out/r2/nb_err.txt
-echo done
+for n in 8388608 4194304; do for k in 2 4 8 16 32 64; do
+  python bench.py --n $n --k $k --steps 100 --warmup 10 --no-cpu --no-ksp > gpurun_out/r2/nb_n${n}_k$k.json 2>/dev/null
+done; done
+python bench.py --n 1048576 --k 32 --partitions 64 --steps 200 --warmup 20 --no-cpu --no-ksp > gpurun_out/r2/nb_c2.json 2>/dev/null

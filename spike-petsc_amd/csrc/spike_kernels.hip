@@ -775,22 +775,31 @@ __device__ __forceinline__ void lu_put(const LuView &v, int64_t rs, int r, int c
     if (slot >= 0 && slot < v.ntl) v.p[v.bb((rs >> 4) + rb, slot, r & 15, c & 15)] = val;
 }
 
-// diagonal-major band -> block-band scratch; one workgroup per 16-row block, the strip transposed through LDS
+// diagonal-major band -> block-band scratch; one workgroup per RB 16-row blocks, the strip transposed through LDS.
+// (RB = 2 -- 256-byte reads -- was measured slower: its strip leaves room for two workgroups per CU only)
+template <int RB>
 __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB, const double *band, int64_t ld, double *T)
 {
-    extern __shared__ double strip[];   // 16 x (W + 1), W = 16 * NTL
-    const int NTL = 2 * KB + 1, W = 16 * NTL, LDW = W + 1;
-    const int64_t rbg = blockIdx.x;
-    const int t = threadIdx.x, row = t & 15, sub = t >> 4;
-    for (int q = t; q < 16 * LDW; q += 256) strip[q] = 0.0;
+    extern __shared__ double strip[];   // 16 RB x (W + 1), W = 16 * NTL + 16 (RB - 1)
+    constexpr int RW = 16 * RB;
+    const int NTL = 2 * KB + 1, W = 16 * NTL + 16 * (RB - 1), LDW = W + 1;
+    const int64_t rbg = (int64_t)blockIdx.x * RB;
+    const int t = threadIdx.x, row = t % RW, sub = t / RW;
+    constexpr int NSUB = 256 / RW;
+    for (int q = t; q < RW * LDW; q += 256) strip[q] = 0.0;
     __syncthreads();
     const int64_t i = rbg * 16 + row;
+    // strip column of entry (row, d): the columns of the strip start at block column (rbg - KB)
     if (i < n)
-        for (int d = sub; d <= 2 * K; d += 16)   // 16 lanes = 16 consecutive rows of one diagonal (128 contiguous bytes)
-            strip[row * LDW + row + d - K + 16 * KB] = band[(int64_t)d * ld + i];
+        for (int d = sub; d <= 2 * K; d += NSUB) strip[row * LDW + row + d - K + 16 * KB] = band[(int64_t)d * ld + i];
     __syncthreads();
-    double *out = T + rbg * NTL * 256;
-    for (int j = 0; j < NTL; ++j) out[j * 256 + t] = strip[(t >> 4) * LDW + 16 * j + (t & 15)];
+#pragma unroll
+    for (int r2 = 0; r2 < RB; ++r2) {
+        if ((rbg + r2) * 16 >= n) break;
+        double *out = T + (rbg + r2) * NTL * 256;
+        // tile j of row block rbg + r2 = block column (rbg + r2) - KB + j = strip columns 16 (r2 + j) ...
+        for (int j = 0; j < NTL; ++j) out[j * 256 + t] = strip[(16 * r2 + (t >> 4)) * LDW + 16 * (r2 + j) + (t & 15)];
+    }
 }
 
 // window width (in 16 x 16 tiles) of the blocked factorisation kernels = half-width of the block-band scratch
@@ -800,12 +809,16 @@ hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t l
 {
     if (n <= 0) return hipSuccess;
     const int KB = lu_kb(K), NTL = 2 * KB + 1;
-    const size_t shm = (size_t)16 * (16 * NTL + 1) * sizeof(double);
+    const int RB = 1;   // measured at the headline size: RB = 2 (256-byte reads, 74 KiB of LDS, two workgroups per CU) 6.9 ms, RB = 1 5.0 ms
+    const size_t shm = (size_t)16 * RB * (16 * NTL + 16 * (RB - 1) + 1) * sizeof(double);
+    const void *fn = RB == 2 ? reinterpret_cast<const void *>(k_band_to_blocks<2>) : reinterpret_cast<const void *>(k_band_to_blocks<1>);
     if (shm > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_to_blocks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_band_to_blocks, dim3((unsigned)((n + 15) / 16)), dim3(256), shm, st, n, K, KB, band, ld, T);
+    const unsigned nwg = (unsigned)(((n + 15) / 16 + RB - 1) / RB);
+    if (RB == 2) hipLaunchKernelGGL(k_band_to_blocks<2>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T);
+    else hipLaunchKernelGGL(k_band_to_blocks<1>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T);
     return hipGetLastError();
 }
 

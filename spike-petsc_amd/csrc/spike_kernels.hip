@@ -790,14 +790,31 @@ __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB
     __syncthreads();
     const int64_t i = rbg * 16 + row;
     // strip column of entry (row, d): the columns of the strip start at block column (rbg - KB)
-    if (i < n)
-        for (int d = sub; d <= 2 * K; d += NSUB) strip[row * LDW + row + d - K + 16 * KB] = band[(int64_t)d * ld + i];
+    // eight diagonals per thread in flight (unconditional loads from clamped addresses, selected afterwards): left as a plain
+    // loop each load waited for the previous LDS store's slot -- 17 memory round trips per workgroup, 5.0 ms at the headline size
+    if (i < n) {
+        const int nd = 2 * K + 1;
+        for (int d0 = sub; d0 < nd; d0 += 8 * NSUB) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * NSUB;
+                v[u] = band[(int64_t)(d < nd ? d : nd - 1) * ld + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * NSUB;
+                if (d < nd) strip[row * LDW + row + d - K + 16 * KB] = v[u];
+            }
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int r2 = 0; r2 < RB; ++r2) {
         if ((rbg + r2) * 16 >= n) break;
         double *out = T + (rbg + r2) * NTL * 256;
         // tile j of row block rbg + r2 = block column (rbg + r2) - KB + j = strip columns 16 (r2 + j) ...
+#pragma unroll 4
         for (int j = 0; j < NTL; ++j) out[j * 256 + t] = strip[(16 * r2 + (t >> 4)) * LDW + 16 * (r2 + j) + (t & 15)];
     }
 }

@@ -1064,10 +1064,9 @@ __device__ __forceinline__ void tile_lu_regs(int s, double *Pd, double *rd, int 
         if (lane < 16) Pd[r * LDT + j] = e[r];
 }
 
-// panel solves of one block step, division-free (rd = reciprocal pivots left by tile_lu_regs):
-// L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
+// one line per thread (the look-ahead kernel at KB = 8 runs at its 168-register cap: two lines per thread spill there)
 template <int KB, int NT>
-__device__ __forceinline__ void panel_solves(const double *Pd, double *Pc, double *Pr, const double *rd, int tid)
+__device__ __forceinline__ void panel_solves1(const double *Pd, double *Pc, double *Pr, const double *rd, int tid)
 {
     for (int t = tid; t < 2 * 16 * KB; t += NT) {
         const int which = t / (16 * KB), idx = t % (16 * KB), tile = idx >> 4, line = idx & 15;
@@ -1100,6 +1099,55 @@ __device__ __forceinline__ void panel_solves(const double *Pd, double *Pc, doubl
             for (int rr = 0; rr < 16; ++rr) T[rr * LDT] = x[rr];
         }
     }
+}
+
+// panel solves of one block step, division-free (rd = reciprocal pivots left by tile_lu_regs):
+// L21 = A21 U11^{-1} (a thread per pair of rows), U12 = L11^{-1} A12 (a thread per pair of columns).
+// TWO lines per thread: every entry of the diagonal tile read from LDS (a broadcast read: all lanes, one address) serves two
+// multiply-adds -- with one line per thread the 136 broadcast reads per line made the LDS pipeline, not the arithmetic, the
+// limit of this phase (4.5 k of the 21.7 k cycles of a block step at K = 128).
+template <int KB, int NT>
+__device__ __forceinline__ void panel_solves2(const double *Pd, double *Pc, double *Pr, const double *rd, int tid)
+{
+    for (int t = tid; t < 16 * KB; t += NT) {          // 2 x (8 KB line pairs)
+        const int which = t / (8 * KB), idx = t % (8 * KB), tile = idx >> 3, line = 2 * (idx & 7);
+        double x[16], y[16];
+        if (which == 0) {
+            double *T = Pc + tile * TS + line * LDT;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { x[c] = T[c]; y[c] = T[LDT + c]; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v = x[c], u = y[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) { const double p = Pd[k * LDT + c]; v -= x[k] * p; u -= y[k] * p; }
+                const double r = rd[c];
+                x[c] = v * r; y[c] = u * r;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { T[c] = x[c]; T[LDT + c] = y[c]; }
+        } else {
+            double *T = Pr + tile * TS + line;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) { x[rr] = T[rr * LDT]; y[rr] = T[rr * LDT + 1]; }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                double v = x[rr], u = y[rr];
+#pragma unroll
+                for (int k = 0; k < rr; ++k) { const double p = Pd[rr * LDT + k]; v -= p * x[k]; u -= p * y[k]; }
+                x[rr] = v; y[rr] = u;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) { T[rr * LDT] = x[rr]; T[rr * LDT + 1] = y[rr]; }
+        }
+    }
+}
+
+template <int KB, int NT, bool TWO = true>
+__device__ __forceinline__ void panel_solves(const double *Pd, double *Pc, double *Pr, const double *rd, int tid)
+{
+    if (TWO) panel_solves2<KB, NT>(Pd, Pc, Pr, rd, tid);
+    else panel_solves1<KB, NT>(Pd, Pc, Pr, rd, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1306,7 +1354,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_factor_mfma_la(LuView lv, con
         const bool more = FAST || s + 1 < nblk;
         // ---- P1(s): L21 = A21 U11^{-1} (one thread per row), U12 = L11^{-1} A12 (one thread per column)
         stamp(s, 0);
-        panel_solves<KB, NT>(Pd, Pc, Pr, rd, tid);
+        panel_solves<KB, NT, (KB < 8)>(Pd, Pc, Pr, rd, tid);
         stamp(s, 1);
         __syncthreads();
         stamp(s, 2);

@@ -215,7 +215,9 @@ def main():
         if not warmed[0]:
             # once per process: a small setup of the same half-bandwidth first, so that setup_s below does not contain the
             # loading of the code object and the runtime's first-use costs (0.4-0.5 s on a fresh box, none of it setup work)
-            wn = 64 * 1024
+            # (a quarter of the local rows, at most 1 M: the allocations of the timed setup are then not the process's first
+            #  large ones either -- on one fresh box the first timed setup took 0.75 s after a 64 K-row warm-up, 0.028 s otherwise)
+            wn = max(64 * 1024, min(1 << 20, (n_local // 4) // 64 * 64))
             w = S.Spike(partitions=0, variant=args.variant)
             w.setup_band(S.gen_band_device(wn, K, seed=1, delta=args.delta))
             w.apply(torch.ones(wn, dtype=torch.float64, device="cuda"))

@@ -3321,7 +3321,7 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
     const bool pair = (r + 1 < m) && ((m & 1) == 0);
     double a0 = 0.0, a1 = 0.0;
     if (pair) {
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < K; ++c) {
             const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(S + (int64_t)c * m));
             a0 = fma(v.x, tip[c], a0);

@@ -2,8 +2,9 @@
 
 config 1 (tridiagonal N=16384, 4 partitions, CPU plumbing) lives in tests/test_oracle.py / test_spike_gpu.py CASES.
 config 4 (MC64 + Fiedler -> band -> PCSPIKE in GMRES) is tests/test_host_gpu.py::test_config4_pipeline_*.
-config 5 (8 GPUs, 8 partitions/GPU) runs here with 8 THREAD ranks on one GPU at N = 2^17 per rank through the
-loopback transport (same algorithm and buffers as the RCCL path)."""
+config 5 (8 GPUs, 8 partitions/GPU) runs here with 8 THREAD ranks on one GPU through the loopback transport (same
+algorithm, buffers and call order as the RCCL path): once at 2^14 rows per rank against the oracle, and once at the
+REAL per-GPU size (N = 2^24, 2^21 rows per rank, ~100 GB of the 288 GB of HBM) through size-independent properties."""
 import threading
 
 import numpy as np
@@ -98,3 +99,56 @@ def test_config5_eight_ranks_eight_partitions_each(spike, oracle):
             raise e
     x = np.concatenate(out)
     assert _rel(x, oracle.Spike(band, G * Pl).apply(f, 1)) <= 1e-10
+
+
+def test_config5_full_size_eight_ranks_on_one_gpu(spike, oracle):
+    """BASELINE config 5 at its real size: N = 2^24, half-bw 128, 8 ranks x 8 partitions, every rank's band generated on
+    the device (bit-identical to the oracle's generator).  Size-independent properties, every one over ALL ranks:
+    M^{-1}(A 1) = 1, residual of a random solve, linearity -- the tips really cross the rank boundaries (a rank that
+    ignored its neighbours would miss 1 by the coupling term)."""
+    import torch
+    G, Pl, K = 8, 8, 128
+    N = 2 ** 24
+    n_rank = N // G
+    v_host = oracle.gen_vec(N)
+    res, err = [None] * G, [None] * G
+
+    def work(r):
+        try:
+            r0 = r * n_rank
+            band = spike.gen_band_device(N, K, seed=12345, delta=1.2, row0=r0, nrows=n_rank)
+            sp = spike.Spike(partitions=Pl)
+            sp.comm_init_local(G, r, 777)
+            sp.setup_band(band, n_global=N, row0=r0)
+            del band
+            i = sp.info()
+            u = torch.ones(n_rank, dtype=torch.float64, device="cuda")
+            b = sp.matvec(u)                      # collective: halo rows come from the neighbouring ranks
+            x = sp.apply(b)                       # collective: tips all-gathered
+            v = torch.from_numpy(v_host[r0:r0 + n_rank].copy()).cuda()
+            bv = sp.matvec(v)
+            xv = sp.apply(bv)
+            rv = sp.matvec(xv) - bv
+            lin = sp.apply(b + 3.0 * bv) - (x + 3.0 * xv)
+            torch.cuda.synchronize()
+            res[r] = dict(err1=float((x - u).abs().max()), r2=float((rv * rv).sum()), b2=float((bv * bv).sum()),
+                          lin=float(lin.abs().max()), errv=float((xv - v).abs().max()), P=i.P_local, chains=i.chains_local,
+                          nranks=i.nranks, Pg=i.P_global, nboost=i.nboost, passes=i.passes, n=i.n_local)
+            sp.close()
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(q is not None for q in res)
+    assert max(q["err1"] for q in res) <= 1e-10
+    assert max(q["errv"] for q in res) <= 1e-10
+    assert np.sqrt(sum(q["r2"] for q in res) / sum(q["b2"] for q in res)) <= 1e-12
+    assert max(q["lin"] for q in res) <= 1e-9
+    for q in res:
+        assert q["P"] == Pl and q["Pg"] == G * Pl and q["nranks"] == G and q["n"] == n_rank and q["nboost"] == 0
+        assert q["chains"] >= Pl and q["chains"] % Pl == 0

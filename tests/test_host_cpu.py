@@ -136,6 +136,7 @@ def test_wbm_ordering_conventions(H):
     H.options()
 
 
+@pytest.mark.hostbox
 def test_vecpermute_matches_matpermute(H):
     # (PA) VecPermute(x, col) = VecPermute(b, row) when A x = b   (the identity KSPSolve_Reorder relies on)
     L = H.lib()
@@ -160,6 +161,7 @@ def test_vecpermute_matches_matpermute(H):
     assert np.array_equal(vx.array, x)
 
 
+@pytest.mark.hostbox
 def test_fiedler_recovers_hidden_band_and_is_deterministic(H):
     n, K = 4000, 6
     rng = np.random.default_rng(0)
@@ -182,6 +184,7 @@ def test_fiedler_recovers_hidden_band_and_is_deterministic(H):
     assert abs(v1.sum()) <= 1e-8 and lam * (1 - 1e-9) <= rho <= 1.25 * lam
 
 
+@pytest.mark.hostbox
 def test_fiedler_halves_is_the_reference_prototype(H):
     """Per-half reordering (src/spectralPartition.c:326-417): Fiedler cut where the vector changes sign, RCM on each half's
     diagonal block, the two permutations composed.  Checked against a direct restatement of those steps."""
@@ -206,6 +209,7 @@ def test_fiedler_halves_is_the_reference_prototype(H):
     assert bw[1] <= 4 * K and bw[3] <= 4 * K
 
 
+@pytest.mark.hostbox
 def test_fiedler_sorted_and_unsorted_rows_and_the_tie_rule(H):
     """Rows with ascending columns take the transpose-and-merge graph build, anything else the general counting-sort build:
     same graph, same bits.  Large components are ordered by a stable radix sort: descending value, ties by index."""
@@ -233,6 +237,7 @@ def test_fiedler_sorted_and_unsorted_rows_and_the_tie_rule(H):
     assert np.array_equal(o, np.argsort(-(v + 0.0), kind="stable")) and sorted(o.tolist()) == list(range(m))
 
 
+@pytest.mark.hostbox
 def test_fiedler_small_exact_and_components(H):
     # path graph on 9 vertices: Fiedler vector is monotone -> the order is the path (up to direction)
     n = 9
@@ -337,6 +342,7 @@ def test_awbm_matches_independent_restatement(H):
     assert np.array_equal(H.is_indices(r), p) and np.array_equal(H.is_indices(c), np.arange(n))
 
 
+@pytest.mark.hostbox
 def test_file_formats_roundtrip(H, tmp_path):
     import ctypes as C
     import struct
@@ -374,6 +380,7 @@ def test_file_formats_roundtrip(H, tmp_path):
     assert L.MatLoad(mm.encode(), C.byref(C.c_void_p())) != 0     # wrong format is an error, not a crash
 
 
+@pytest.mark.hostbox
 def test_rcm_reduces_bandwidth_like_scipy(H):
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     n, K = 3000, 5

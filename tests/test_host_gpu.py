@@ -49,6 +49,23 @@ def _testbed2(H, A, **opts):
     return err.value, its.value, reason.value, ksp, M
 
 
+def _banded_line(H, ksp, tmp_path):
+    """(k, kmax, frac) of the PCBANDED somewhere below `ksp`, parsed from KSPView's output"""
+    import re
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    path = str(tmp_path / "view.txt")
+    fp = libc.fopen(path.encode(), b"w")
+    assert fp
+    H.chk(H.lib().KSPView(ksp, C.c_void_p(fp)))
+    libc.fclose(C.c_void_p(fp))
+    m = re.search(r"Banded: k = (\d+) \((\d+) max\), frac = (\S+) ", open(path).read())
+    assert m, open(path).read()
+    return int(m.group(1)), int(m.group(2)), float(m.group(3))
+
+
 def test_banded_pc_on_banded_matrix(H, oracle):
     # src/makefile:18: -ksp_type gmres -ksp_rtol 1.0e-5 -ksp_max_it 500 with -pc_type banded
     N, K = 20000, 20
@@ -129,6 +146,32 @@ def test_config4_pipeline_mc64_fiedler_band_gmres(H, oracle):
     err2, its2, reason2, ksp2, _ = _testbed2(H, A, ksp_type="gmres", ksp_rtol=1e-5, ksp_max_it=60, pc_type="none")
     assert reason2 != 2 or its2 > its
     H.chk(L.KSPDestroy(C.byref(ksp2)))
+
+
+def test_config4_pipeline_at_asic320k_size(H, tmp_path):
+    """BASELINE config 4 at the SIZE of ASIC_320k (n = 321 821; the file itself is not available offline, the circuit-like
+    stand-in has its row/nonzero counts): wbm (MC64 job 5 as a row permutation) -> fiedler / rcm -> band extraction
+    (kmax 50) -> PCSPIKE inside GMRES(30), rtol 1e-5, max_it 500 (src/makefile:18), all through nested KSPREORDER options."""
+    L = H.lib()
+    n = 321821
+    A = circuit_like(n, seed=7, band=24)
+    assert (np.abs(A.diagonal()) == 0).sum() > n // 2
+    for second in ("fiedler", "rcm"):
+        opts = dict(ksp_type="reorder", mat_ordering_type="wbm", mat_wbm_rows=1,
+                    reorder_ksp_type="reorder", reorder_mat_ordering_type=second,
+                    reorder_reorder_ksp_type="gmres", reorder_reorder_ksp_rtol=1e-5, reorder_reorder_ksp_max_it=500,
+                    reorder_reorder_pc_type="banded", reorder_reorder_pc_banded_kmax=50)
+        err, its, reason, ksp, M = _testbed2(H, A, **opts)
+        assert reason == 2 and its <= 60, (second, err, its, reason)
+        assert err <= 1e-3 * np.sqrt(n), (second, err)
+        # the banded PC found a band: read "Banded: k = .. (.. max), frac = .." off KSPView (kspreorder.c:155-170 nests the
+        # inner views, matbanded.c:196-211 prints the line)
+        k, kmax, frac = _banded_line(H, ksp, tmp_path)
+        assert 0 < k <= 50 and kmax == 50 and frac > 0.5, (second, k, frac)
+        r, c = C.c_void_p(), C.c_void_p()
+        H.chk(L.KSPReorderGetOrdering(ksp, C.byref(r), C.byref(c)))
+        assert sorted(H.is_indices(r).tolist()) == list(range(n))
+        H.chk(L.KSPDestroy(C.byref(ksp)))
 
 
 def test_c_driver_testbed2_runs_the_reference_pipeline(H, tmp_path):

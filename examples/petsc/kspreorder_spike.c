@@ -2,7 +2,9 @@
  * kspreorder_spike.c -- PETSc glue: KSPREORDER (/root/reference/src/kspreorder.c) for a current PETSc, with the
  * reordering kernels of this repository behind MatGetOrdering.
  *
- * NOT BUILT IN THIS REPOSITORY (PETSc is installed on neither box); it is the file a maintainer of
+ * NOT BUILT IN THIS REPOSITORY (PETSc is installed on neither box; tests/test_petsc_glue_syntax.py runs a
+ * `gcc -fsyntax-only` TYPO CHECK of it against the declarations-only header examples/petsc/syntax_check/, for a 32-bit and
+ * a 64-bit PetscInt -- a typo check, not a build and not an oracle); it is the file a maintainer of
  * spikegpu/spike-petsc drops next to src/kspreorder.c, beside pcbanded_spike.c.  The reference's file mixes PETSc 3.4
  * and 3.5 calls and compiles against no release; this one is written against PETSc >= 3.19
  * (PetscCall, 3-argument KSPSetOperators, PetscOptionsHeadBegin).  Structure, option names, prefixes and the in-place
@@ -13,7 +15,23 @@
  */
 #include <petsc/private/kspimpl.h>
 #include <petscmat.h>
-#include <spike_petsc_host.h> /* spike_mc64_job5, spike_awbm, spike_fiedler_order, spike_rcm_order: plain C, no PETSc types */
+#include <spike_orderings.h> /* spike_mc64_job5[_i32], spike_awbm[_i32], spike_fiedler_order_ex/_i32: plain C, no PETSc types */
+
+/* PetscInt is 32-bit in PETSc's DEFAULT build, 64-bit with --with-64-bit-indices: one entry point of the library for each.
+   (Never cast a PetscInt array to int64_t*: with 32-bit indices the kernels would read past ia/ja and write 8-byte values
+   into the 4-byte perm/order arrays.) */
+#if defined(PETSC_USE_64BIT_INDICES)
+typedef int64_t SpikeIdx;
+#define spike_mc64_job5X(n, ia, ja, a, perm, u, v, num) spike_mc64_job5(n, ia, ja, a, perm, u, v, num)
+#define spike_awbmX(n, ia, ja, a, perm)                 spike_awbm(n, ia, ja, a, perm, NULL, NULL)
+#define spike_fiedler_orderX(n, ia, ja, a, order)       spike_fiedler_order_ex(n, ia, ja, a, order, NULL, 1)
+#else
+typedef int32_t SpikeIdx;
+#define spike_mc64_job5X(n, ia, ja, a, perm, u, v, num) spike_mc64_job5_i32(n, ia, ja, a, perm, u, v, num)
+#define spike_awbmX(n, ia, ja, a, perm)                 spike_awbm_i32(n, ia, ja, a, perm, NULL, NULL)
+#define spike_fiedler_orderX(n, ia, ja, a, order)       spike_fiedler_order_i32(n, ia, ja, a, order, NULL, 1)
+#endif
+typedef char SpikeIdxMatchesPetscInt[(sizeof(SpikeIdx) == sizeof(PetscInt)) ? 1 : -1];
 
 typedef struct {
   KSP  ksp;            /* :4 the embedded KSP */
@@ -44,7 +62,8 @@ static PetscErrorCode SpikeRestoreCSR(Mat mat, PetscInt *n, const PetscInt **ia,
 
 PETSC_EXTERN PetscErrorCode MatGetOrdering_WBM(Mat mat, MatOrderingType type, IS *row, IS *col) /* src/petsc_mat_wbm.c:13 */
 {
-  PetscInt        n, num = 0;
+  PetscInt        n;
+  SpikeIdx        num = 0;
   const PetscInt *ia, *ja;
   PetscScalar    *a;
   PetscInt       *perm;
@@ -53,7 +72,7 @@ PETSC_EXTERN PetscErrorCode MatGetOrdering_WBM(Mat mat, MatOrderingType type, IS
   PetscCall(SpikeGetCSR(mat, &n, &ia, &ja, &a));
   PetscCall(PetscMalloc3(n, &perm, n, &u, n, &v));
   /* the CSR arrays go where MC64 expects CSC, as in the reference (:52): MC64 works on the transpose */
-  PetscCheck(spike_mc64_job5((int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a, (int64_t *)perm, u, v, (int64_t *)&num) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_mc64_job5 failed");
+  PetscCheck(spike_mc64_job5X((SpikeIdx)n, (const SpikeIdx *)ia, (const SpikeIdx *)ja, a, (SpikeIdx *)perm, u, v, &num) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_mc64_job5 failed");
   PetscCall(ISCreateStride(PETSC_COMM_SELF, n, 0, 1, row));                     /* :57 */
   PetscCall(ISCreateGeneral(PETSC_COMM_SELF, n, perm, PETSC_COPY_VALUES, col)); /* :58 */
   PetscCall(PetscFree3(perm, u, v));                                            /* scalings dropped as :56,59 */
@@ -70,7 +89,7 @@ PETSC_EXTERN PetscErrorCode MatGetOrdering_Fiedler(Mat mat, MatOrderingType type
   PetscFunctionBegin;
   PetscCall(SpikeGetCSR(mat, &n, &ia, &ja, &a));
   PetscCall(PetscMalloc1(n, &order));
-  PetscCheck(spike_fiedler_order((int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a, (int64_t *)order, NULL) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_fiedler_order failed");
+  PetscCheck(spike_fiedler_orderX((SpikeIdx)n, (const SpikeIdx *)ia, (const SpikeIdx *)ja, a, (SpikeIdx *)order) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_fiedler_order failed");
   PetscCall(ISCreateGeneral(PETSC_COMM_SELF, n, order, PETSC_OWN_POINTER, row)); /* :54 */
   PetscCall(PetscObjectReference((PetscObject)*row));                            /* the same IS for rows and columns, :55-56 */
   *col = *row;
@@ -87,7 +106,7 @@ PETSC_EXTERN PetscErrorCode MatGetOrdering_AWBM(Mat mat, MatOrderingType type, I
   PetscFunctionBegin;
   PetscCall(SpikeGetCSR(mat, &n, &ia, &ja, &a));
   PetscCall(PetscMalloc1(n, &perm));
-  PetscCheck(spike_awbm((int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a, (int64_t *)perm, NULL, NULL) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_awbm failed");
+  PetscCheck(spike_awbmX((SpikeIdx)n, (const SpikeIdx *)ia, (const SpikeIdx *)ja, a, (SpikeIdx *)perm) == 0, PETSC_COMM_SELF, PETSC_ERR_LIB, "spike_awbm failed");
   PetscCall(ISCreateStride(PETSC_COMM_SELF, n, 0, 1, row));
   PetscCall(ISCreateGeneral(PETSC_COMM_SELF, n, perm, PETSC_OWN_POINTER, col)); /* src/petsc_mat_awbm.c:202 */
   PetscCall(SpikeRestoreCSR(mat, &n, &ia, &ja, &a));

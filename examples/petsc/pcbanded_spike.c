@@ -1,7 +1,9 @@
 /*
  * pcbanded_spike.c -- PETSc glue: PCBANDED with libspike_mi355.so as its inner preconditioner.
  *
- * NOT BUILT IN THIS REPOSITORY (PETSc is installed on neither box); it is the file a maintainer of
+ * NOT BUILT IN THIS REPOSITORY (PETSc is installed on neither box; tests/test_petsc_glue_syntax.py runs a
+ * `gcc -fsyntax-only` TYPO CHECK of it against the declarations-only header examples/petsc/syntax_check/, for a 32-bit and
+ * a 64-bit PetscInt -- a typo check, not a build and not an oracle); it is the file a maintainer of
  * spikegpu/spike-petsc drops next to src/matbanded.c.  It replaces the embedded `PC pc` of PC_Banded
  * (/root/reference/src/matbanded.c:111-116) by a spike_handle and maps the ops table 1:1 onto
  * include/spike_mi355.h.  Written against the PETSc >= 3.19 API (PetscCall, PETSC_SUCCESS); line numbers
@@ -15,6 +17,93 @@
 #include <petsc/private/pcimpl.h>
 #include <petscdevice_hip.h>
 #include <spike_mi355.h>
+
+/* PetscInt is 32-bit in PETSc's DEFAULT build and 64-bit with --with-64-bit-indices: the library has an entry point for
+   each, selected here at compile time.  (Never cast a PetscInt array to int64_t*: with 32-bit indices the library would
+   read past ia/ja.) */
+#if defined(PETSC_USE_64BIT_INDICES)
+typedef int64_t SpikeIdx;
+#define spike_setup_csr_distX    spike_setup_csr_dist
+#define spike_csr_band_weightsX  spike_csr_band_weights
+#else
+typedef int32_t SpikeIdx;
+#define spike_setup_csr_distX    spike_setup_csr_dist32
+#define spike_csr_band_weightsX  spike_csr_band_weights32
+#endif
+typedef char SpikeIdxMatchesPetscInt[(sizeof(SpikeIdx) == sizeof(PetscInt)) ? 1 : -1];
+
+/* MatCreateSubMatrixBanded (/root/reference/src/matbanded.h:5, src/matbanded.c:22-107; called directly by
+   src/testbed.c:286-296): the half-bandwidth rule on the library's host code (per-rank weights in row order, combined in
+   RANK order so that every rank chooses the same k -- the reference's own weight Vec is indexed locally, :45, and is only
+   right on one rank), then the copy of the |c - r| <= k entries into a new AIJ matrix with PETSc calls (:65-99).
+   In: *kmax, *frac as the reference; out: *kmax = k (:104), *frac = achieved fraction (:105), *B. */
+PetscErrorCode MatCreateSubMatrixBanded(Mat A, PetscInt *kmax, PetscReal *frac, Mat *B)
+{
+  MPI_Comm        comm = PetscObjectComm((PetscObject)A);
+  Mat             Aloc = A;
+  PetscBool       ismpi, done;
+  PetscInt        N, n, rstart, rend, r, c, ncols, nb, *dnnz, *onnz, *bcols;
+  const PetscInt *ia, *ja, *cols;
+  PetscScalar    *a, *bvals;
+  const PetscScalar *vals;
+  PetscMPIInt     size, q;
+  double         *part, *all, *w, normA = 0.0, f = 0.0;
+  int             k = 0, km = (int)*kmax, d;
+
+  PetscFunctionBegin;
+  PetscCallMPI(MPI_Comm_size(comm, &size));
+  PetscCall(MatGetSize(A, &N, NULL));
+  PetscCall(MatGetOwnershipRange(A, &rstart, &rend)); /* :36 */
+  PetscCall(PetscObjectTypeCompare((PetscObject)A, MATMPIAIJ, &ismpi));
+  if (ismpi) PetscCall(MatMPIAIJGetLocalMat(A, MAT_INITIAL_MATRIX, &Aloc));
+  PetscCall(MatGetRowIJ(Aloc, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
+  PetscCheck(done && n == rend - rstart, comm, PETSC_ERR_SUP, "MatGetRowIJ failed");
+  PetscCall(MatSeqAIJGetArray(Aloc, &a));
+  /* passes 1 and 2 (:38-56): [w[0..kmax) | normA] per rank, gathered, added in rank order */
+  PetscCall(PetscCalloc3(km + 1, &part, (size_t)(km + 1) * size, &all, km > 0 ? km : 1, &w));
+  PetscCheck(spike_csr_band_weightsX((int64_t)N, (int64_t)rstart, (int64_t)n, (const SpikeIdx *)ia, (const SpikeIdx *)ja, a, km, part, &part[km]) == 0,
+             comm, PETSC_ERR_ARG_OUTOFRANGE, "MatCreateSubMatrixBanded: column index out of range");
+  PetscCallMPI(MPI_Allgather(part, km + 1, MPI_DOUBLE, all, km + 1, MPI_DOUBLE, comm));
+  for (q = 0; q < size; ++q) {
+    for (d = 0; d < km; ++d) w[d] += all[(size_t)q * (km + 1) + d];
+    normA += all[(size_t)q * (km + 1) + km];
+  }
+  PetscCheck(spike_band_rule((int64_t)N, w, normA, km, (double)*frac, &k, &f) == 0, comm, PETSC_ERR_LIB, "spike_band_rule failed");
+  PetscCall(PetscFree3(part, all, w));
+  PetscCall(MatSeqAIJRestoreArray(Aloc, &a));
+  PetscCall(MatRestoreRowIJ(Aloc, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
+  if (ismpi) PetscCall(MatDestroy(&Aloc));
+  /* pass 3 (:65-99): count, preallocate, copy */
+  PetscCall(PetscCalloc2(n, &dnnz, n, &onnz));
+  for (r = rstart; r < rend; ++r) {
+    PetscCall(MatGetRow(A, r, &ncols, &cols, NULL));
+    for (c = 0; c < ncols; ++c)
+      if (PetscAbsInt(cols[c] - r) <= (PetscInt)k) { if (cols[c] >= rstart && cols[c] < rend) ++dnnz[r - rstart]; else ++onnz[r - rstart]; } /* :73-75 */
+    PetscCall(MatRestoreRow(A, r, &ncols, &cols, NULL));
+  }
+  PetscCall(MatCreate(comm, B));
+  PetscCall(MatSetSizes(*B, n, n, N, N));
+  PetscCall(MatSetType(*B, MATAIJ));
+  PetscCall(MatXAIJSetPreallocation(*B, 1, dnnz, onnz, NULL, NULL)); /* :81 */
+  PetscCall(PetscMalloc2(2 * (size_t)k + 1, &bcols, 2 * (size_t)k + 1, &bvals));
+  for (r = rstart; r < rend; ++r) {
+    PetscCall(MatGetRow(A, r, &ncols, &cols, &vals));
+    for (nb = 0, c = 0; c < ncols; ++c)
+      if (PetscAbsInt(cols[c] - r) <= (PetscInt)k) {
+        PetscCheck(nb < 2 * (PetscInt)k + 1, comm, PETSC_ERR_PLIB, "row %" PetscInt_FMT " holds more than 2k+1 band entries", r); /* :95 */
+        bcols[nb] = cols[c]; bvals[nb] = vals[c]; ++nb;
+      }
+    PetscCall(MatSetValues(*B, 1, &r, nb, bcols, bvals, INSERT_VALUES)); /* :98 */
+    PetscCall(MatRestoreRow(A, r, &ncols, &cols, &vals));
+  }
+  PetscCall(PetscFree2(bcols, bvals));
+  PetscCall(PetscFree2(dnnz, onnz));
+  PetscCall(MatAssemblyBegin(*B, MAT_FINAL_ASSEMBLY));
+  PetscCall(MatAssemblyEnd(*B, MAT_FINAL_ASSEMBLY));
+  *kmax = (PetscInt)k; /* :104 */
+  *frac = (PetscReal)f; /* :105 */
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
 
 typedef struct {
   PetscInt     kmax, k;   /* :112 */
@@ -115,13 +204,13 @@ static PetscErrorCode PCSetUp_Banded(PC pc) /* :165-180 */
   if (ismpi) PetscCall(MatMPIAIJGetLocalMat(pc->pmat, MAT_INITIAL_MATRIX, &Aloc)); /* diagonal + off-diagonal block merged, global columns (:74-75) */
   /* MatCreateSubMatrixBanded (:22-107) + PCSetUp(b->pc) (:178) in one call: the library applies the reference's
      half-bandwidth rule to the CSR arrays (per-rank sums combined in rank order) and factors the extracted band on the
-     GPU.  Needs --with-64-bit-indices (PetscInt = int64_t); otherwise widen ia/ja first. */
+     GPU.  The entry point matches sizeof(PetscInt) (SpikeIdx above). */
   PetscCall(MatGetRowIJ(Aloc, 0, PETSC_FALSE, PETSC_FALSE, &n, &ia, &ja, &done));
   PetscCheck(done && n == rend - rstart, PetscObjectComm((PetscObject)pc), PETSC_ERR_SUP, "MatGetRowIJ failed");
   PetscCall(MatSeqAIJGetArray(Aloc, &a));
   b->k = b->kmax; b->f = b->frac; /* :172-173 */
-  SPIKE_CHK(pc, b, spike_setup_csr_dist(b->spike, (int64_t)N, (int64_t)rstart, (int64_t)n, (const int64_t *)ia, (const int64_t *)ja, a,
-                                        (int)b->kmax, (double)b->frac, &k, &f));
+  SPIKE_CHK(pc, b, spike_setup_csr_distX(b->spike, (int64_t)N, (int64_t)rstart, (int64_t)n, (const SpikeIdx *)ia, (const SpikeIdx *)ja, a,
+                                         (int)b->kmax, (double)b->frac, &k, &f));
   b->k = k; b->f = f;
   PetscCall(PetscInfo(pc, "PCBANDED: half-bandwidth: %d norm fraction: %g\n", k, f)); /* :175 */
   PetscCall(MatSeqAIJRestoreArray(Aloc, &a));

@@ -1,0 +1,1 @@
+#include "petsc_decls_only.h" /* declarations only: see that file */

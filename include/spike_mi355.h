@@ -122,9 +122,10 @@ int spike_setup_band(spike_handle h, int64_t n_global, int64_t row0, int64_t n_l
 
 /* CSR entry (single rank): band extraction with the reference's rule, then spike_setup_band.
  * kmax/frac as PCBANDED's -pc_banded_kmax/-pc_banded_frac (defaults 50 / 0.95).
- * ia/ja are 0-based int64 host arrays.  Precondition (what an assembled AIJ matrix gives, MatGetRow at matbanded.c:40):
- * a row holds a column at most once.  A repeated (row, column) pair is summed on the device with fp64 atomics, i.e. in
- * no fixed order: the band then agrees with the sequential sum to rounding only, not bit for bit.            */
+ * ia/ja are 0-based int64 host arrays.  An assembled AIJ matrix holds a column at most once per row (MatGetRow at
+ * matbanded.c:40); if a (row, column) pair is repeated anyway, the band keeps the LAST stored value -- the INSERT_VALUES
+ * semantics of the reference's MatSetValues (matbanded.c:98) -- deterministically (one thread per row, storage order);
+ * the half-bandwidth rule's weights count every stored entry.                                                  */
 int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t *ja, const double *a,
                     int kmax, double frac, int *k_out, double *frac_out);
 
@@ -135,6 +136,13 @@ int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, const int64_t 
  * combined in rank order, so every rank chooses the same k.  One rank: identical to spike_setup_csr.            */
 int spike_setup_csr_dist(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia,
                          const int64_t *ja, const double *a, int kmax, double frac, int *k_out, double *frac_out);
+
+/* The same two entry points for 32-bit index arrays -- PETSc's DEFAULT build has a 32-bit PetscInt (the glue in
+ * examples/petsc/ selects on sizeof(PetscInt)).  row0 / n_global stay 64-bit: several ranks may hold > 2^31 rows. */
+int spike_setup_csr32(spike_handle h, int64_t n, const int32_t *ia, const int32_t *ja, const double *a,
+                      int kmax, double frac, int *k_out, double *frac_out);
+int spike_setup_csr_dist32(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, const int32_t *ia,
+                           const int32_t *ja, const double *a, int kmax, double frac, int *k_out, double *frac_out);
 
 /* ---- apply --------------------------------------------------------------------------- */
 /* y = M^{-1} x on the local rows.  x != y.  on_device != 0: device pointers, asynchronous on
@@ -178,6 +186,11 @@ int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja, const dou
 int spike_csr_band_weights(int64_t n_global, int64_t row0, int64_t n_local, const int64_t *ia, const int64_t *ja,
                            const double *a, int kmax, double *w, double *normA);
 int spike_band_rule(int64_t n, const double *w, double normA, int kmax, double frac, int *k_out, double *frac_out);
+/* 32-bit index variants of the rule (MatCreateSubMatrixBanded in the PETSc glue of a default PETSc build) */
+int spike_csr_band_k32(int64_t n, const int32_t *ia, const int32_t *ja, const double *a, int kmax, double frac,
+                       int *k_out, double *frac_out);
+int spike_csr_band_weights32(int64_t n_global, int64_t row0, int64_t n_local, const int32_t *ia, const int32_t *ja,
+                             const double *a, int kmax, double *w, double *normA);
 
 /* ---- helpers (device) ----------------------------------------------------------------------- */
 /* y = A x with the band kept at setup (device pointers, local rows; halo via RCCL when nranks>1) */

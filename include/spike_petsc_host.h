@@ -24,6 +24,7 @@
 #define SPIKE_PETSC_HOST_H
 #include <stdint.h>
 #include <stdio.h>
+#include "spike_orderings.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -160,25 +161,8 @@ PetscErrorCode KSPCreate_Reorder(KSP ksp);
 PetscErrorCode KSPCreate_GMRES(KSP ksp);
 PetscErrorCode KSPReorderGetOrdering(KSP ksp, IS *row, IS *col); /* borrowed references */
 
-/* the two vendored-kernel replacements, usable on their own */
-int spike_mc64_job5(int64_t n, const int64_t *colptr, const int64_t *rowind, const double *val, int64_t *perm,
-                    double *u, double *v, int64_t *num);
-int spike_awbm(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, double *sr, double *sc);
-int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec);
-/* use_device != 0 and a HIP device present: the LOBPCG refinement of the large multilevel levels runs on the GPU
- * (libspike_mi355: spike_fd_*), with a bit-identical permutation */
-int spike_fiedler_order_ex(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec,
-                           int use_device);
-int spike_rcm_order(int64_t n, const int64_t *ia, const int64_t *ja, int64_t *order);
-/* Fiedler bisection + reverse Cuthill-McKee on each half's diagonal block, composed -- the per-half reordering prototyped
- * in src/spectralPartition.c:326-417.  pos_size: rows in the positive half; halves_bw[4] (optional): bandwidth of the
- * positive / negative block before and after its own reordering.  Ordering name in the registry: "fiedler_halves". */
-int spike_fiedler_halves_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order,
-                               int64_t *pos_size, int64_t *halves_bw, int use_device);
+/* the ordering kernels themselves (plain C, no PETSc types): include/spike_orderings.h */
 PetscErrorCode MatGetOrdering_FiedlerHalves(Mat A, MatOrderingType type, IS *row, IS *col);
-int spike_profile_bandwidth(int64_t n, const int64_t *ia, const int64_t *ja, const int64_t *order, int64_t *profile,
-                            int64_t *bandwidth);
-
 #ifdef __cplusplus
 }
 #endif

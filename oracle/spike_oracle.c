@@ -417,14 +417,15 @@ void orc_band_extract_fill(i64 n, const i64 *ia, const i64 *ja, const double *a,
     ib[n] = q;
 }
 
-/* CSR -> diagonal-major band with half-bandwidth K (entries outside are dropped; duplicates add) */
+/* CSR -> diagonal-major band with half-bandwidth K (entries outside are dropped; a repeated (row, column) pair keeps
+   the LAST value: MatSetValues(..., INSERT_VALUES), matbanded.c:98) */
 void orc_csr_to_band(i64 n, const i64 *ia, const i64 *ja, const double *a, int K, double *band, i64 ld)
 {
     for (int d = 0; d <= 2 * K; ++d) memset(band + (size_t)d * ld, 0, sizeof(double) * (size_t)n);
     for (i64 r = 0; r < n; ++r)
         for (i64 p = ia[r]; p < ia[r + 1]; ++p) {
             const i64 d = ja[p] - r + K;
-            if (d >= 0 && d <= 2 * K) band[(size_t)d * ld + r] += a[p];
+            if (d >= 0 && d <= 2 * K) band[(size_t)d * ld + r] = a[p];
         }
 }
 

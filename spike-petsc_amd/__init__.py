@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "spike_dev_download", "spike_csr_band_k", "spike_csr_to_band", "spike_measure_read_bw",
     "spike_set_operator_band", "spike_operator_matvec", "spike_auto_partitions",
     "spike_setup_csr_dist", "spike_csr_band_weights", "spike_band_rule",
+    "spike_setup_csr32", "spike_setup_csr_dist32", "spike_csr_band_k32", "spike_csr_band_weights32",
     "spike_device_count", "spike_fd_create", "spike_fd_destroy", "spike_fd_dots", "spike_fd_lap", "spike_fd_shift",
     "spike_fd_div", "spike_fd_fill_alternating", "spike_fd_download_x", "spike_fd_refine",
 ]
@@ -96,6 +97,12 @@ def lib():
                                   C.POINTER(C.c_double)]
     L.spike_setup_csr_dist.argtypes = [vp, i64, i64, i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                        C.POINTER(C.c_double)]
+    i32p = C.POINTER(C.c_int32)
+    L.spike_setup_csr32.argtypes = [vp, i64, i32p, i32p, dptr, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.spike_setup_csr_dist32.argtypes = [vp, i64, i64, i64, i32p, i32p, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_double)]
+    L.spike_csr_band_k32.argtypes = [i64, i32p, i32p, dptr, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.spike_csr_band_weights32.argtypes = [i64, i64, i64, i32p, i32p, dptr, C.c_int, dptr, dptr]
     L.spike_csr_band_weights.argtypes = [i64, i64, i64, iptr, iptr, dptr, C.c_int, dptr, dptr]
     L.spike_band_rule.argtypes = [i64, dptr, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.spike_apply.argtypes = [vp, vp, vp, C.c_int]
@@ -205,6 +212,18 @@ class Spike:
         f = C.c_double(0)
         self._chk(self.L.spike_setup_csr(self.h, n, ia.ctypes.data_as(iptr), ja.ctypes.data_as(iptr),
                                          a.ctypes.data_as(dptr), kmax, frac, C.byref(k), C.byref(f)))
+        return k.value, f.value
+
+    def setup_csr32(self, n, ia, ja, a, kmax=50, frac=0.95):
+        """the 32-bit index entry point (PETSc's default PetscInt)"""
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ja = np.ascontiguousarray(ja, dtype=np.int32)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        k = C.c_int(0)
+        f = C.c_double(0)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.L.spike_setup_csr32(self.h, n, ia.ctypes.data_as(i32p), ja.ctypes.data_as(i32p),
+                                           a.ctypes.data_as(dptr), kmax, frac, C.byref(k), C.byref(f)))
         return k.value, f.value
 
     def setup_csr_dist(self, n_global, row0, ia, ja, a, kmax=50, frac=0.95):

@@ -81,8 +81,34 @@ extern "C" int spike_csr_to_band(int64_t n, const int64_t *ia, const int64_t *ja
     for (int64_t r = 0; r < n; ++r)
         for (int64_t p = ia[r]; p < ia[r + 1]; ++p) {
             const int64_t d = ja[p] - r + K;
-            if (d >= 0 && d <= 2 * K) band[(size_t)d * ld + r] += a[p];
+            if (d >= 0 && d <= 2 * K) band[(size_t)d * ld + r] = a[p];   // a repeated pair keeps the last value (INSERT_VALUES, :98)
         }
     return SPIKE_OK;
 }
 
+
+// 32-bit index variants (PETSc's default PetscInt): the same rule on widened copies
+static void widen(int64_t n, const int32_t *ia, const int32_t *ja, std::vector<int64_t> &ia64, std::vector<int64_t> &ja64)
+{
+    ia64.resize((size_t)n + 1);
+    for (int64_t i = 0; i <= n; ++i) ia64[(size_t)i] = ia[i];
+    const int64_t nnz = ia64[(size_t)n] > 0 ? ia64[(size_t)n] : 0;
+    ja64.resize((size_t)(nnz > 0 ? nnz : 1));
+    for (int64_t q = 0; q < nnz; ++q) ja64[(size_t)q] = ja[q];
+}
+extern "C" int spike_csr_band_k32(int64_t n, const int32_t *ia, const int32_t *ja, const double *a, int kmax, double frac,
+                                  int *k_out, double *frac_out)
+{
+    if (n <= 0 || !ia || !ja) return SPIKE_ERR_ARG;
+    std::vector<int64_t> ia64, ja64;
+    widen(n, ia, ja, ia64, ja64);
+    return spike_csr_band_k(n, ia64.data(), ja64.data(), a, kmax, frac, k_out, frac_out);
+}
+extern "C" int spike_csr_band_weights32(int64_t n_global, int64_t row0, int64_t n_local, const int32_t *ia, const int32_t *ja,
+                                        const double *a, int kmax, double *w, double *normA)
+{
+    if (n_local < 0 || !ia || !ja) return SPIKE_ERR_ARG;
+    std::vector<int64_t> ia64, ja64;
+    widen(n_local, ia, ja, ia64, ja64);
+    return spike_csr_band_weights(n_global, row0, n_local, ia64.data(), ja64.data(), a, kmax, w, normA);
+}

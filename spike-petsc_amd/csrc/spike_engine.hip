@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -311,11 +312,12 @@ struct TmpPool {
             if (q == (void *)p) { (void)hipFree(q); q = nullptr; }
         p = nullptr;
     }
-    ~TmpPool()
+    void release_all()
     {
-        for (void *q : ptrs)
-            if (q) (void)hipFree(q);
+        for (auto &q : ptrs)
+            if (q) { (void)hipFree(q); q = nullptr; }
     }
+    ~TmpPool() { release_all(); }
 };
 
 static void free_factors(spike_handle h)
@@ -854,7 +856,9 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->nboost = (int64_t)nb;
-    // (the LU scratch stays alive until the spike columns are done: the block-TRSM reads the factors in their tile form)
+    // (the block-band LU scratch stays alive until the spike columns are done: the block-TRSM reads the factors in their
+    //  tile form; the diagonal-major scratch of K <= 32 has no reader left)
+    if (!lu_blk) tmp.release(dLU);
 
     mark("pack");
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
@@ -973,6 +977,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             }
             if (bad != 0.0) {
                 h->profile = keep_prof;
+                // the redo allocates its own LU scratch, probe vectors and descriptors: give this attempt's back first
+                // (otherwise two LU scratches + the band + the factors are alive at once on this path only)
+                HIPCHK(hipStreamSynchronize(st));
+                tmp.release_all();
                 return setup_impl(h, n_global, row0, n, K, band, ld, on_device, false);
             }
         }
@@ -1660,8 +1668,14 @@ extern "C" int spike_setup_csr_dist(spike_handle h, int64_t n_global, int64_t ro
         if ((rc = spike_band_rule(n_global, w.data(), normA, kmax, frac, &k, &f))) return fail(h, rc, "band rule failed");
     }
     const int64_t nnz = ia[n_local];
+    // columns go up RELATIVE to this rank's first row and clamped into int32: an in-band entry lies in [-k, n_local + k]
+    // whatever n_global is (several ranks may hold more than 2^31 rows together); a clamped value is out of band for
+    // every row (n_local <= 2e9), so the device drops it like any other out-of-band entry
     std::vector<int32_t> j32((size_t)nnz);
-    for (int64_t q = 0; q < nnz; ++q) j32[(size_t)q] = (int32_t)ja[q];
+    for (int64_t q = 0; q < nnz; ++q) {
+        const int64_t rel = ja[q] - row0;
+        j32[(size_t)q] = (int32_t)(rel < -(int64_t)(1 << 30) ? -(int64_t)(1 << 30) : rel > (int64_t)INT32_MAX ? (int64_t)INT32_MAX : rel);
+    }
     TmpPool tmp;
     int64_t *dia = nullptr;
     int32_t *dja = nullptr;
@@ -1673,7 +1687,7 @@ extern "C" int spike_setup_csr_dist(spike_handle h, int64_t n_global, int64_t ro
     HIPCHK(hipMemcpyAsync(dia, ia, sizeof(int64_t) * (n_local + 1), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(dja, j32.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
-    HIPCHK(launch_csr_to_band(n_local, dia, dja, da, k, dband, n_local, st, row0));
+    HIPCHK(launch_csr_to_band(n_local, dia, dja, da, k, dband, n_local, st));
     HIPCHK(hipStreamSynchronize(st));
     const int keep = h->keep_band;
     h->keep_band = 1;  // dband is scratch: the library must hold its own copy
@@ -1692,6 +1706,28 @@ extern "C" int spike_setup_csr(spike_handle h, int64_t n, const int64_t *ia, con
 {
     if (h && h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "several ranks: every rank passes its row block to spike_setup_csr_dist");
     return spike_setup_csr_dist(h, n, 0, n, ia, ja, a, kmax, frac, k_out, frac_out);
+}
+
+// 32-bit index entry points: PETSc's default build has a 32-bit PetscInt.  Same calls, the index arrays widened here
+// (one pass over ia/ja on the host; the device copy is 32-bit columns either way).
+extern "C" int spike_setup_csr_dist32(spike_handle h, int64_t n_global, int64_t row0, int64_t n_local, const int32_t *ia,
+                                      const int32_t *ja, const double *a, int kmax, double frac, int *k_out, double *frac_out)
+{
+    if (!h || n_local <= 0 || !ia || !ja) return fail(h, SPIKE_ERR_ARG, "spike_setup_csr_dist32: bad sizes");
+    std::vector<int64_t> ia64((size_t)n_local + 1);
+    for (int64_t i = 0; i <= n_local; ++i) ia64[(size_t)i] = ia[i];
+    const int64_t nnz = ia64[(size_t)n_local];
+    if (nnz < 0) return fail(h, SPIKE_ERR_ARG, "spike_setup_csr_dist32: ia[n_local] < 0");
+    std::vector<int64_t> ja64((size_t)(nnz > 0 ? nnz : 1));
+    for (int64_t q = 0; q < nnz; ++q) ja64[(size_t)q] = ja[q];
+    return spike_setup_csr_dist(h, n_global, row0, n_local, ia64.data(), ja64.data(), a, kmax, frac, k_out, frac_out);
+}
+
+extern "C" int spike_setup_csr32(spike_handle h, int64_t n, const int32_t *ia, const int32_t *ja, const double *a, int kmax,
+                                 double frac, int *k_out, double *frac_out)
+{
+    if (h && h->nranks > 1) return fail(h, SPIKE_ERR_ARG, "several ranks: every rank passes its row block to spike_setup_csr_dist32");
+    return spike_setup_csr_dist32(h, n, 0, n, ia, ja, a, kmax, frac, k_out, frac_out);
 }
 
 // ---- introspection ---------------------------------------------------------------------------------------------

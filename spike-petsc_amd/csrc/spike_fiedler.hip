@@ -433,7 +433,7 @@ extern "C" int spike_fd_create(int64_t n, const int64_t *xadj, const int64_t *ad
               hipMalloc((void **)&c->dchunk, sizeof(double) * (size_t)(MAXD * c->nchunks)) == hipSuccess &&
               hipHostMalloc((void **)&c->hchunk, sizeof(double) * (size_t)(MAXD * c->nchunks), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&c->dstate, sizeof(fd_state)) == hipSuccess &&
-              hipHostMalloc((void **)&c->hstate, sizeof(fd_state), hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void **)&c->hstate, 2 * sizeof(fd_state), hipHostMallocDefault) == hipSuccess;
     for (int q = 0; q < 7 && ok; ++q) ok = hipMalloc((void **)&c->v[q], sizeof(double) * (size_t)n) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_fd_fill_one, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, c->v[6]);
@@ -500,8 +500,12 @@ extern "C" int spike_fd_download_x(spike_fd_ctx *c, double *x)
     return SPIKE_OK;
 }
 
-// ---- a level's whole refinement loop, launched blind: maxit x (six vector steps, each with its scalar step), then the
-// final scaling; the state (fiedler_steer.h) lives in device memory.  One synchronisation at the end (its = iterations run).
+// ---- a level's whole refinement loop without a host round trip per iteration: (six vector steps, each with its scalar
+// step) per iteration, the state (fiedler_steer.h) in device memory, then the final scaling.  The iterations are enqueued in
+// CHUNKS of 32; after each chunk the state is copied to one of two pinned slots, and the host looks at chunk c's copy only
+// after chunk c+1 is in the queue -- the GPU never waits for the host, and a level whose stopping test fires early costs at
+// most two chunks of no-op launches instead of the rest of maxit (up to 1000 x 14).  The no-op steps change nothing, so the
+// result is the same bits whatever the chunking.
 extern "C" int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int maxit, int *its)
 {
     if (!c || maxit < 0) return SPIKE_ERR_ARG;
@@ -513,7 +517,10 @@ extern "C" int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int max
     double **v = c->v;
     fd_state *st = c->dstate;
     const int64_t n = c->n, nch = c->nchunks;
-    for (int it = 0; it < maxit; ++it) {
+    constexpr int CHUNK = 32;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) FDCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    auto iteration = [&]() {
         hipLaunchKernelGGL(k_fd_resid_precond, gc, b, 0, c->st, n, st, v[0], v[1], c->deg, v[2], out);
         hipLaunchKernelGGL((k_fd_steer<0, 2>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
         hipLaunchKernelGGL(k_fd_shift_dots, gc, b, 0, c->st, n, st, v[2], v[0], v[4], out);
@@ -528,7 +535,21 @@ extern "C" int spike_fd_refine(spike_fd_ctx *c, double dmax, double rho, int max
         hipLaunchKernelGGL((k_fd_steer<4, 6>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
         hipLaunchKernelGGL(k_fd_update_xx, gc, b, 0, c->st, n, st, v[0], v[1], v[2], v[3], v[4], v[5], out);
         hipLaunchKernelGGL((k_fd_steer<5, 1>), dim3(1), b, 0, c->st, st, c->dchunk, nch);
+    };
+    int rc = SPIKE_OK;
+    int q = 0;   // chunks enqueued
+    for (int it0 = 0; it0 < maxit && rc == SPIKE_OK; it0 += CHUNK, ++q) {
+        const int it1 = it0 + CHUNK < maxit ? it0 + CHUNK : maxit;
+        for (int it = it0; it < it1; ++it) iteration();
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&c->hstate[q & 1], st, sizeof h, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+            hipEventRecord(ev[q & 1], c->st) != hipSuccess) { rc = SPIKE_ERR_HIP; break; }
+        if (q >= 1) {   // chunk q is in the queue: now the host may wait for chunk q-1's state
+            if (hipEventSynchronize(ev[(q - 1) & 1]) != hipSuccess) { rc = SPIKE_ERR_HIP; break; }
+            if (c->hstate[(q - 1) & 1].done) { ++q; break; }   // the stopping test fired: chunk q is all no-ops, nothing more to enqueue
+        }
     }
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
+    if (rc != SPIKE_OK) { (void)hipStreamSynchronize(c->st); return rc; }
     hipLaunchKernelGGL(k_fd_final_scale, ge, b, 0, c->st, n, st, v[0], v[1]);
     FDCHK(hipGetLastError());
     FDCHK(hipMemcpyAsync(c->hstate, st, sizeof h, hipMemcpyDeviceToHost, c->st));

@@ -139,8 +139,9 @@ hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hip
 // Krylov pieces (spike_krylov.hip)
 hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int tpr, const double *x,
                              double *y, hipStream_t st);
+// ja = column - (first row of the rank), clamped into int32 (spike_setup_csr_dist); last value wins for a repeated pair
 hipError_t launch_csr_to_band(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int K, double *band,
-                              int64_t ld, hipStream_t st, int64_t row0 = 0);
+                              int64_t ld, hipStream_t st);
 // deterministic grid reductions: ws = red_workspace_doubles() doubles of per-workgroup partials
 size_t red_workspace_doubles();
 hipError_t launch_dots(const double *V, int64_t ldv, int nvec, const double *w, int64_t n, double *out /*nvec*/,

@@ -281,27 +281,27 @@ hipError_t launch_csr_matvec(int64_t n, const int64_t *ia, const int32_t *ja, co
 
 // CSR -> diagonal-major band on the device (spike_setup_csr): lane = nonzero within a row group, rows by TPR lanes;
 // entries outside |c - r| <= K are dropped, duplicates add (as MatSetValues(ADD) would).
-// Local rows [row0, row0 + n) of a row-block-distributed matrix, GLOBAL column indices (row0 = 0: the whole matrix).
-// Precondition (AIJ guarantees it): a row does not repeat a column -- repeated entries would be summed by atomics in
-// an order that is not fixed.
-__global__ __launch_bounds__(256) void k_csr_to_band(int64_t n, int64_t row0, const int64_t *ia, const int32_t *ja,
-                                                     const double *a, int K, double *band, int64_t ld)
+// Local rows [row0, row0 + n) of a row-block-distributed matrix.  ja holds the column RELATIVE to the rank's first row
+// (global column - row0, clamped into int32 by the host: an in-band entry lies in [-K, n + K], whatever n_global is).
+// One thread per row, entries in storage order, plain stores: a repeated (row, column) pair keeps the LAST value -- the
+// INSERT_VALUES semantics of the reference's MatSetValues (src/matbanded.c:98) -- and the result is the same bits every run.
+__global__ __launch_bounds__(256) void k_csr_to_band(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int K,
+                                                     double *band, int64_t ld)
 {
-    const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 4;
-    const int sub = threadIdx.x % 4;
+    const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (row >= n) return;
-    for (int64_t k = ia[row] + sub; k < ia[row + 1]; k += 4) {
-        const int64_t d = (int64_t)ja[k] - (row0 + row) + K;
-        if (d >= 0 && d <= 2 * K) atomicAdd(band + d * ld + row, a[k]);
+    for (int64_t k = ia[row]; k < ia[row + 1]; ++k) {
+        const int64_t d = (int64_t)ja[k] - row + K;
+        if (d >= 0 && d <= 2 * K) band[d * ld + row] = a[k];
     }
 }
 
 hipError_t launch_csr_to_band(int64_t n, const int64_t *ia, const int32_t *ja, const double *a, int K, double *band,
-                              int64_t ld, hipStream_t st, int64_t row0)
+                              int64_t ld, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(band, 0, sizeof(double) * (size_t)(2 * K + 1) * (size_t)ld, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_csr_to_band, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, n, row0, ia, ja, a, K, band, ld);
+    hipLaunchKernelGGL(k_csr_to_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ia, ja, a, K, band, ld);
     return hipGetLastError();
 }
 

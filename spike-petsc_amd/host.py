@@ -28,7 +28,7 @@ HOST_SYMBOLS = [
     "KSPAppendOptionsPrefix", "KSPSetOperators", "KSPGetPC", "KSPSetTolerances", "KSPSetFromOptions", "KSPSetUp",
     "KSPSolve", "KSPGetConvergedReason", "KSPGetIterationNumber", "KSPGetResidualNorm", "KSPView", "KSPDestroy",
     "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order", "spike_fiedler_order_ex", "spike_fiedler_halves_order", "MatGetOrdering_FiedlerHalves",
-    "spike_profile_bandwidth", "spike_awbm", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
+    "spike_profile_bandwidth", "spike_awbm", "spike_mc64_job5_i32", "spike_awbm_i32", "spike_fiedler_order_i32", "spike_rcm_order_i32", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
 ]
 
 _L = None

@@ -74,3 +74,44 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(128, 524288) == 182     # N/8 rows per GPU of the headline: 182 chains of 2880 rows, not 128 of 4096
     assert L.spike_auto_partitions(32, 2 ** 20) == 512     # BASELINE config 2: a chain keeps >= 64 K rows (measured: 512 chains 0.138 ms, 1024 0.162)
     assert L.spike_auto_partitions(300, N) < 0             # K > 256 is refused
+
+
+def test_band_rule_32bit_indices_and_last_value_wins(spike, oracle):
+    """spike_csr_band_k32 / spike_csr_band_weights32 (PETSc's default 32-bit PetscInt) equal the 64-bit rule; the host
+    CSR -> band conversion keeps the LAST value of a repeated (row, column) pair (INSERT_VALUES, matbanded.c:98), like the
+    oracle and like the device scatter."""
+    import ctypes as C
+    L = spike.lib()
+    rng = np.random.default_rng(3)
+    n = 400
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j in range(max(0, i - 9), min(n, i + 10)):
+            rows.append(i); cols.append(j); vals.append(float(rng.choice([1.0, 0.5, -0.25])) if i != j else 4.0)
+    ia = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ia, np.array(rows) + 1, 1)
+    ia = np.cumsum(ia)
+    ja, a = np.array(cols, dtype=np.int64), np.array(vals)
+    k64, f64 = spike.csr_band_k(n, ia, ja, a, kmax=50, frac=0.9)
+    i32p, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    ia32, ja32 = ia.astype(np.int32), ja.astype(np.int32)
+    k, f = C.c_int(0), C.c_double(0)
+    assert L.spike_csr_band_k32(n, ia32.ctypes.data_as(i32p), ja32.ctypes.data_as(i32p), a.ctypes.data_as(dp), 50, 0.9,
+                                C.byref(k), C.byref(f)) == 0
+    assert (k.value, f.value) == (k64, f64)
+    w64, w32, n64, n32 = np.zeros(50), np.zeros(50), C.c_double(0), C.c_double(0)
+    i64p = C.POINTER(C.c_int64)
+    assert L.spike_csr_band_weights(n, 0, n, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp), 50,
+                                    w64.ctypes.data_as(dp), C.byref(n64)) == 0
+    assert L.spike_csr_band_weights32(n, 0, n, ia32.ctypes.data_as(i32p), ja32.ctypes.data_as(i32p), a.ctypes.data_as(dp), 50,
+                                      w32.ctypes.data_as(dp), C.byref(n32)) == 0
+    assert np.array_equal(w64, w32) and n64.value == n32.value
+    # a repeated pair: the last stored value is the band's value
+    ia2 = np.array([0, 3, 5], dtype=np.int64)
+    ja2 = np.array([0, 1, 0, 0, 1], dtype=np.int64)
+    a2 = np.array([1.0, 2.0, 7.0, 3.0, 4.0])
+    band = np.zeros((3, 2))
+    assert L.spike_csr_to_band(2, ia2.ctypes.data_as(i64p), ja2.ctypes.data_as(i64p), a2.ctypes.data_as(dp), 1,
+                               band.ctypes.data_as(dp), 2) == 0
+    assert band[1, 0] == 7.0 and band[2, 0] == 2.0 and band[0, 1] == 3.0 and band[1, 1] == 4.0
+    assert np.array_equal(band, oracle.csr_to_band(2, ia2, ja2, a2, 1))

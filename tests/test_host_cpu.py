@@ -398,3 +398,52 @@ def test_rcm_reduces_bandwidth_like_scipy(H):
     C2 = sp.block_diag([B[:50, :50], B[:30, :30], sp.eye(1)]).tocsr()
     o = H.rcm_order(81, C2.indptr, C2.indices)
     assert sorted(o) == list(range(81))
+
+
+@pytest.mark.hostbox
+def test_32bit_index_entry_points_equal_the_64bit_ones(H):
+    """PETSc's default build has a 32-bit PetscInt: the _i32 entry points (csrc/host/idx32.c) must give the 64-bit kernels'
+    results on the same matrix (they widen, call, narrow).  Guard words around the 4-byte output arrays catch an 8-byte
+    write (what casting a PetscInt* to int64_t* did in round 2's glue)."""
+    import ctypes as C
+    L = H.lib()
+    i32p = C.POINTER(C.c_int32)
+    dpp = C.POINTER(C.c_double)
+    n = 3000
+    A = circuit_like(n, seed=4)
+    ia32, ja32 = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    a = np.ascontiguousarray(A.data, dtype=np.float64)
+
+    def guarded():
+        buf = np.full(n + 2, -77, dtype=np.int32)
+        return buf, buf[1:n + 1]
+
+    # MC64 job 5
+    p64, u64, v64, num64 = H.mc64_job5(n, A.indptr, A.indices, A.data)
+    buf, perm = guarded()
+    u, v, num = np.zeros(n), np.zeros(n), C.c_int32(0)
+    assert L.spike_mc64_job5_i32(n, ia32.ctypes.data_as(i32p), ja32.ctypes.data_as(i32p), a.ctypes.data_as(dpp),
+                                 perm.ctypes.data_as(i32p), u.ctypes.data_as(dpp), v.ctypes.data_as(dpp), C.byref(num)) == 0
+    assert buf[0] == -77 and buf[-1] == -77
+    assert np.array_equal(perm.astype(np.int64), p64) and num.value == num64 and np.array_equal(u, u64) and np.array_equal(v, v64)
+    # AWBM
+    buf, perm = guarded()
+    assert L.spike_awbm_i32(n, ia32.ctypes.data_as(i32p), ja32.ctypes.data_as(i32p), a.ctypes.data_as(dpp),
+                            perm.ctypes.data_as(i32p), None, None) == 0
+    assert buf[0] == -77 and buf[-1] == -77 and np.array_equal(perm.astype(np.int64), H.awbm(n, A.indptr, A.indices, A.data))
+    # Fiedler, RCM on the symmetrised pattern
+    S = sp.csr_matrix(A + A.T)
+    S.sort_indices()
+    sa32, sj32 = S.indptr.astype(np.int32), S.indices.astype(np.int32)
+    sd = np.ascontiguousarray(S.data, dtype=np.float64)
+    buf, order = guarded()
+    vec = np.zeros(n)
+    assert L.spike_fiedler_order_i32(n, sa32.ctypes.data_as(i32p), sj32.ctypes.data_as(i32p), sd.ctypes.data_as(dpp),
+                                     order.ctypes.data_as(i32p), vec.ctypes.data_as(dpp), 0) == 0
+    o64, v64 = H.fiedler_order(n, S.indptr, S.indices, S.data)
+    assert buf[0] == -77 and buf[-1] == -77 and np.array_equal(order.astype(np.int64), o64) and np.array_equal(vec, v64)
+    buf, order = guarded()
+    assert L.spike_rcm_order_i32(n, sa32.ctypes.data_as(i32p), sj32.ctypes.data_as(i32p), order.ctypes.data_as(i32p)) == 0
+    assert buf[0] == -77 and buf[-1] == -77 and np.array_equal(order.astype(np.int64), H.rcm_order(n, S.indptr, S.indices))
+    # bad input is refused, not read
+    assert L.spike_rcm_order_i32(0, sa32.ctypes.data_as(i32p), sj32.ctypes.data_as(i32p), order.ctypes.data_as(i32p)) != 0

@@ -264,6 +264,23 @@ def test_setup_csr_uses_reference_rule(spike, oracle, torch_cuda):
     rhs = oracle.gen_vec(n)
     assert _rel(sp.apply(rhs), oracle.Spike(band, 4).apply(rhs, 1)) <= TOL
     assert sp.info().k_extracted == ko
+    # the 32-bit index entry point (PETSc's default PetscInt) is the same setup
+    sp32 = spike.Spike(partitions=4)
+    k32, f32 = sp32.setup_csr32(n, ia, ja, a, kmax=50, frac=0.95)
+    assert (k32, f32) == (k, f)
+    assert np.array_equal(sp32.apply(rhs), sp.apply(rhs))
+    # a repeated (row, column) pair keeps the LAST stored value (INSERT_VALUES, matbanded.c:98), the same bits every run
+    ia2 = ia.copy(); ia2[1:] += 1
+    ja2 = np.concatenate([[ja[0]], ja]); a2 = np.concatenate([[123.0], a])      # row 0 stores its first entry twice
+    spd = spike.Spike(partitions=4)
+    kd, fd = spd.setup_csr(n, ia2, ja2, a2, kmax=50, frac=1.0)
+    assert kd == 30
+    band_d = oracle.csr_to_band(n, ia2, ja2, a2, kd)
+    assert band_d[kd + int(ja[0]), 0] == a[0]
+    x1 = spd.apply(rhs)
+    assert _rel(x1, oracle.Spike(band_d, 4).apply(rhs, 1)) <= TOL
+    spd.setup_csr(n, ia2, ja2, a2, kmax=50, frac=1.0)
+    assert np.array_equal(spd.apply(rhs), x1)
 
 
 def test_full_size_properties(spike, oracle, torch_cuda):

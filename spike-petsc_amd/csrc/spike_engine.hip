@@ -128,6 +128,7 @@ struct spike_handle_s {
     int subsplit = 1;           // 1 = cut a caller-chosen partition into sub-chains when the spikes provably die inside them
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
     double spike_tol = 1e-16;   // relative magnitude below which spike rows are dropped (fp64 rounding level)
+    int twist_opt = 1;          // 1 = twisted (two-ended) factorisation of chain PAIRS where setup finds it applicable, 0 = never
     hipStream_t stream = nullptr;
     int overlap = 1;            // multi-rank apply: exchange + rank-boundary interfaces on a second stream beside the local coupling work
     hipStream_t stream2 = nullptr;
@@ -142,6 +143,16 @@ struct spike_handle_s {
     int64_t n_global = 0, row0 = 0, n = 0;
     int K = 0, P = 0;           // P = chains the kernels sweep
     int P_user = 0, S = 1;      // the caller's partitions and how many chains each one is cut into (P = P_user * S)
+    // Twisted factorisation: chains 2t and 2t+1 are the top and the bottom half of ONE diagonal block, factored from its two
+    // ends towards the seam between them.  Both halves sweep inward in the forward launch, a 2K x 2K seam system (exact, not
+    // truncated) links them, both sweep outward in the backward launch: two workgroups per block, but only the blocks' OUTER
+    // ends are truncated interfaces with stored spikes -- half the spike traffic of the same number of ordinary chains.
+    bool twisted = false;
+    std::vector<ChainDesc> chainsV;   // the chains with the identity vector map (setup works in factor space); == chains unless twisted
+    ChainDesc *dChainsV = nullptr;    // device copy (aliases dChains unless twisted)
+    IfaceDesc *dIfsSeam = nullptr;    // one per pair: the seam system on the intermediate vector, solved in place
+    double *dSeamWT = nullptr, *dSeamVT = nullptr, *dSeamST = nullptr;
+    int nseam = 0;
     SweepCfg cfg{64, 32, 1};
     std::vector<ChainDesc> chains;
     std::vector<GroupDesc> groups;
@@ -325,9 +336,11 @@ static void free_factors(spike_handle h)
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     if (h->ownA) F(h->dA); else h->dA = nullptr;
     h->ownA = false;
+    if (h->dChainsV == h->dChains) h->dChainsV = nullptr;   // an alias unless twisted
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dTips1); F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
+    F(h->dChainsV); F(h->dIfsSeam); F(h->dSeamWT); F(h->dSeamVT); F(h->dSeamST); h->nseam = 0; h->twisted = false; h->chainsV.clear();
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
     F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
     for (int i = 0; i < 2; ++i) if (h->hostDots[i]) { (void)hipHostFree(h->hostDots[i]); h->hostDots[i] = nullptr; }
@@ -417,6 +430,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "subsplit") h->subsplit = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
+    else if (k == "twist") h->twist_opt = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
@@ -584,10 +598,38 @@ static int build_chains(spike_handle h)
     const int R = h->cfg.R, CPW = h->cfg.CPW();
     const int64_t nblk = (n + BLK - 1) / BLK;
     if (nblk < PU) return fail(h, SPIKE_ERR_PARTITION, "%d partitions need at least %d blocks of 64 rows, have %lld", PU, PU, (long long)nblk);
+    const bool tw = h->twisted;
+    if (tw && (S % 2 != 0 || nblk < (int64_t)P)) return fail(h, SPIKE_ERR_PARTITION, "internal: twisted factorisation needs an even chain count per partition");
     h->chains.resize(P);
+    // a chain's first / last vector-space row has a neighbour iff it is not the first / last row of the whole system
+    auto top_flag = [&](int64_t first_row) { return (h->row0 + first_row > 0) ? CHAIN_HAS_TOP : 0; };
+    auto bot_flag = [&](int64_t end_row) { return (h->row0 + end_row < h->n_global) ? CHAIN_HAS_BOT : 0; };
     for (int pu = 0; pu < PU; ++pu) {
         // the caller's partition pu = 64-row blocks [b0,b1); its S chains split that block range evenly
         const int64_t b0 = (nblk * (int64_t)pu) / PU, b1 = (nblk * (int64_t)(pu + 1)) / PU;
+        if (tw) {
+            // S/2 diagonal blocks, each cut in the middle into a top half (factored downward) and a bottom half (factored
+            // upward from the block's last row: chain-local row 0 = that row)
+            const int NP = S / 2;
+            for (int t = 0; t < NP; ++t) {
+                const int64_t pb0 = b0 + ((b1 - b0) * t) / NP, pb1 = b0 + ((b1 - b0) * (t + 1)) / NP;
+                const int64_t qb = (pb0 + pb1 + 1) / 2;
+                const int pd = pu * S + 2 * t, pq = pd + 1;
+                const int64_t r0 = pb0 * BLK, q = qb * BLK;
+                int64_t r1 = pb1 * BLK;
+                if (r1 > n || pq == P - 1) r1 = n;
+                if (q - r0 < (h->K > 1 ? h->K : 1) || r1 - q < (h->K > 1 ? h->K : 1))
+                    return fail(h, SPIKE_ERR_PARTITION, "partition %d: a half of %lld / %lld rows < K=%d", pu, (long long)(q - r0), (long long)(r1 - q), h->K);
+                ChainDesc &cdn = h->chains[pd], &cup = h->chains[pq];
+                cdn.row0 = r0; cdn.nrows = (int32_t)(q - r0); cdn.vec0 = r0; cdn.vdir = 1;
+                cdn.flags = top_flag(r0) | CHAIN_HAS_BOT;
+                cup.row0 = q; cup.nrows = (int32_t)(r1 - q); cup.vec0 = r1 - 1; cup.vdir = -1;
+                cup.flags = (bot_flag(r1) ? CHAIN_HAS_TOP : 0) | CHAIN_HAS_BOT;
+                cdn.nsteps = (int32_t)((cdn.nrows + R - 1) / R);
+                cup.nsteps = (int32_t)((cup.nrows + R - 1) / R);
+            }
+            continue;
+        }
         for (int sidx = 0; sidx < S; ++sidx) {
             const int p = pu * S + sidx;
             int64_t r0 = (b0 + ((b1 - b0) * sidx) / S) * BLK, r1 = (b0 + ((b1 - b0) * (sidx + 1)) / S) * BLK;
@@ -598,8 +640,13 @@ static int build_chains(spike_handle h)
             h->chains[p].row0 = r0;
             h->chains[p].nrows = (int32_t)rows;
             h->chains[p].nsteps = (int32_t)((rows + R - 1) / R);
+            h->chains[p].vec0 = r0;
+            h->chains[p].vdir = 1;
+            h->chains[p].flags = top_flag(r0) | bot_flag(r1);
         }
     }
+    h->chainsV = h->chains;
+    for (auto &c : h->chainsV) { c.vec0 = c.row0; c.vdir = 1; }
     const int ng = (P + CPW - 1) / CPW;
     h->groups.resize(ng);
     int64_t t0 = 0, ms = 0;
@@ -654,7 +701,9 @@ struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes a
 static int run_pass(spike_handle h, const double *in, double *out, bool with_corr, const SubChains *sub = nullptr)
 {
     SweepArgs a;
-    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = h->P; a.K = h->K;
+    // PCApply sweeps the caller's vectors (chains with their vector map); setup's solves live in factor space
+    const ChainDesc *base_chains = h->ready ? h->dChains : h->dChainsV;
+    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : base_chains; a.nchains = h->P; a.K = h->K;
     a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
     a.corr_top = with_corr ? h->dCorrTop : nullptr;
     a.corr_bot = with_corr ? h->dCorrBot : nullptr;
@@ -684,6 +733,9 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, st, tag));
     else HIPCHK(launch_sweep(h->cfg, false, ng, a, st, tag));
     rec(false);
+    // twisted: both halves of every diagonal block have swept inward; their seam systems (2K x 2K, exact) are solved in
+    // place on the intermediate vector, then both halves sweep outward
+    if (h->twisted && h->ready && !sub) HIPCHK(launch_iface_apply(h->K, h->nseam, h->dIfsSeam, h->dY, st));
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
@@ -738,7 +790,7 @@ __global__ void k_build_xh(const double *x, int64_t n, int K, const double *recv
 
 // ---- setup -----------------------------------------------------------------------------------------------
 static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n, int K, const double *band, int64_t ld,
-                      int on_device, bool allow_subsplit = true)
+                      int on_device, bool allow_subsplit = true, bool allow_twist = true)
 {
     if (!h) return SPIKE_ERR_ARG;
     if (n <= 0 || n_global < n || row0 < 0 || row0 + n > n_global || K < 0 || !band || ld < n)
@@ -769,27 +821,55 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     const int ncu = device_cus();
     h->P_user = h->opt_partitions > 0 ? h->opt_partitions : auto_partitions(cfg, K, n, ncu);
     h->S = 1;
+    h->twisted = false;
     int rc = SPIKE_OK;
+    // min over the ranks of a small non-negative integer (ranks must walk the same branches of the collective steps below)
+    auto agree_min = [&](int mine, int *out) -> int {
+        *out = mine;
+        if (!exchanging(h)) return SPIKE_OK;
+        double *dS = nullptr;
+        HIPCHK(tmp.alloc(&dS, 1));
+        const double neg = -(double)mine;
+        HIPCHK(hipMemcpyAsync(dS, &neg, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        int r2 = coll_allreduce(h, dS, 1, NCCL_MAX);
+        if (r2) return r2;
+        double got = 0.0;
+        HIPCHK(hipMemcpyAsync(&got, dS, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *out = (int)(-got);
+        tmp.release(dS);
+        return SPIKE_OK;
+    };
+    // Twisted factorisation (handle comment): needs stored spikes (one-pass coupled apply), the tile sweeps (K >= 2), and for
+    // K > 32 chain lengths that are multiples of 16 (the seam matrices come from the blocked TRSM) -- chain boundaries are
+    // multiples of 64 except the end of the last chain, i.e. n.  Whether the spikes really die inside a half is measured
+    // below; if not, setup starts over without twisting.
+    bool can_twist = h->twist_opt && allow_twist && !cfg.scan && K >= 2 && h->spike_storage &&
+                     (K <= 32 || (n % 16 == 0 && getenv("SPIKE_NO_TRSM") == nullptr)) && getenv("SPIKE_NO_TWIST") == nullptr;
     if (h->opt_partitions > 0 && h->subsplit && allow_subsplit && K > 0) {
         // A caller-chosen P may leave most CUs without a chain.  Cut every partition into S chains; the cuts are
         // treated like partition interfaces (truncated coupling), which reproduces the P-partition preconditioner to
         // rounding iff the spikes die inside a chain -- measured below, and undone (S = 1) when they do not.
+        // Ranks may own different row counts and would pick different S; the probe / redo below is collective
+        // (allreduce + a second setup), so every rank must walk the same branches: all take the smallest S.
         int S = pick_subsplit(cfg, K, n, h->P_user, ncu);
-        if (exchanging(h)) {
-            // Ranks may own different row counts and would pick different S; the probe / redo below is collective
-            // (allreduce + a second setup), so every rank must walk the same branches: all take the smallest S.
-            double *dS = nullptr;
-            HIPCHK(tmp.alloc(&dS, 1));
-            const double neg = -(double)S;
-            HIPCHK(hipMemcpyAsync(dS, &neg, sizeof(double), hipMemcpyHostToDevice, h->stream));
-            if ((rc = coll_allreduce(h, dS, 1, NCCL_MAX))) return rc;
-            double got = 0.0;
-            HIPCHK(hipMemcpyAsync(&got, dS, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            S = (int)(-got);
-            tmp.release(dS);
-        }
+        if ((rc = agree_min(S, &S))) return rc;
         if (S > 1) h->S = S;
+    }
+    {
+        // chains per partition must be even to pair them up: an odd S >= 3 gives one chain away (S = 1: nothing to pair --
+        // cutting a partition only to twist it gains nothing: same number of truncated interfaces, more seams)
+        int tw = 0;
+        if (can_twist) {
+            if (h->opt_partitions > 0) tw = (h->S >= 2) ? 1 : 0;
+            else tw = (h->P_user >= 2) ? 1 : 0;
+        }
+        if ((rc = agree_min(tw, &tw))) return rc;
+        if (tw) {
+            if (h->opt_partitions > 0) { if (h->S % 2) --h->S; }
+            else { h->S = 2; h->P_user /= 2; }     // the library's own choice: the same chains, paired into P/2 diagonal blocks
+            h->twisted = true;
+        }
     }
     rc = build_chains(h);
     if (rc) return rc;
@@ -815,6 +895,21 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(dalloc(&h->dGroups, h->groups.size()));
     HIPCHK(upload(h, h->dChains, h->chains.data(), sizeof(ChainDesc) * P, st));
     HIPCHK(upload(h, h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), st));
+    const bool tw = h->twisted;
+    // setup works in FACTOR space: the chains with the identity vector map, and -- twisted -- a copy of the band in which
+    // the bottom halves are stored flipped, so that factorisation, packing and the spike solves run unchanged
+    h->dChainsV = h->dChains;
+    const double *bandF = h->dA;
+    int64_t ldF = h->ldA;
+    double *dAv = nullptr;
+    if (tw) {
+        h->dChainsV = nullptr;
+        HIPCHK(dalloc(&h->dChainsV, (size_t)P));
+        HIPCHK(upload(h, h->dChainsV, h->chainsV.data(), sizeof(ChainDesc) * P, st));
+        HIPCHK(tmp.alloc(&dAv, (size_t)nd * n));
+        HIPCHK(launch_band_flip(h->dA, h->ldA, K, h->dChains, P, h->max_chain_rows, dAv, n, st));
+        bandF = dAv; ldF = n;
+    }
 
     mark("band copy");
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
@@ -832,11 +927,11 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     double *dLU = nullptr;
     const size_t lu_blk = lu_blocks_doubles(n, K);   // K > 32: block-band scratch (dense 16 x 16 tiles), made in one transposing pass
     HIPCHK(tmp.alloc(&dLU, lu_blk ? lu_blk : (size_t)nd * n));
-    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, h->dA, h->ldA, dLU, st));
-    else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
+    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, bandF, ldF, dLU, st));
+    else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), bandF, ldF * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
-    HIPCHK(launch_factor(dLU, n, K, h->dChains, P, boost, dNb, st));
+    HIPCHK(launch_factor(dLU, n, K, h->dChainsV, P, boost, dNb, st));
     mark("LU copy + factor");
     // scan path (K = 1): "tiles" are plain per-row arrays, dLt = l, dUt = c
     const size_t tile_total = cfg.scan ? (size_t)n : (size_t)h->ntiles * (size_t)cfg.tile_doubles();
@@ -850,34 +945,58 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
         HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
     }
-    if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChains, P, h->dLt, h->dUt, h->dDinv, st));
-    else HIPCHK(launch_pack(cfg, dLU, n, K, h->dChains, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
+    if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChainsV, P, h->dLt, h->dUt, h->dDinv, st));
+    else HIPCHK(launch_pack(cfg, dLU, n, K, h->dChainsV, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
     unsigned long long nb = 0;
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     h->nboost = (int64_t)nb;
     // (the block-band LU scratch stays alive until the spike columns are done: the block-TRSM reads the factors in their
     //  tile form; the diagonal-major scratch of K <= 32 has no reader left)
-    if (!lu_blk) tmp.release(dLU);
+    if (!lu_blk && !tw) tmp.release(dLU);   // (twisted: the seam matrices of K <= 32 are read off it further down)
 
     mark("pack");
     // ---- spike tips, coupling blocks, interface systems --------------------------------------------
     const bool multi = exchanging(h);
-    const int nif_local = P - 1;
+    // truncated interfaces between this rank's chains: every chain boundary, or -- twisted -- every boundary between PAIRS
+    const int nif_local = tw ? P / 2 - 1 : P - 1;
     const int nif = (K > 0) ? nif_local + (multi && h->rank > 0 ? 1 : 0) + (multi && h->rank < h->nranks - 1 ? 1 : 0) : 0;
     h->nif = nif;
     const size_t kk = (size_t)K * K;
-    if (K > 0) {
+    if (K > 0 && !tw) {
         HIPCHK(dalloc(&h->dCorrTop, (size_t)P * K));
         HIPCHK(dalloc(&h->dCorrBot, (size_t)P * K));
         HIPCHK(hipMemsetAsync(h->dCorrTop, 0, sizeof(double) * P * K, st));
         HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
     }
-    if (nif > 0) {
+    // starting over without twisting / without sub-splitting: this attempt's scratch goes back first (otherwise two LU
+    // scratches + the band + the factors are alive at once on this path only)
+    auto redo = [&](bool sub_ok, bool twist_ok) -> int {
+        HIPCHK(hipStreamSynchronize(st));
+        tmp.release_all();
+        return setup_impl(h, n_global, row0, n, K, band, ld, on_device, sub_ok, twist_ok);
+    };
+    // a yes/no every rank must answer alike (a redo is a second, collective setup): true if ANY rank says so
+    auto any_rank = [&](bool mine, double *dflag, bool *out) -> int {
+        *out = mine;
+        if (!exchanging(h)) return SPIKE_OK;
+        const double v = mine ? 1.0 : 0.0;
+        HIPCHK(hipMemcpyAsync(dflag, &v, sizeof(double), hipMemcpyHostToDevice, st));
+        int r2 = coll_allreduce(h, dflag, 1, NCCL_MAX);
+        if (r2) return r2;
+        double got = 0.0;
+        HIPCHK(hipMemcpyAsync(&got, dflag, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *out = got != 0.0;
+        return SPIKE_OK;
+    };
+    if (nif > 0 || tw) {
         HIPCHK(dalloc(&h->dWt, (size_t)P * kk));
         HIPCHK(dalloc(&h->dVb, (size_t)P * kk));
-        HIPCHK(dalloc(&h->dBT, (size_t)P * kk));
-        HIPCHK(dalloc(&h->dCT, (size_t)P * kk));
+        if (!tw) {
+            HIPCHK(dalloc(&h->dBT, (size_t)P * kk));
+            HIPCHK(dalloc(&h->dCT, (size_t)P * kk));
+        }
         HIPCHK(hipMemsetAsync(h->dWt, 0, sizeof(double) * P * kk, st));
         HIPCHK(hipMemsetAsync(h->dVb, 0, sizeof(double) * P * kk, st));
         double *rhs = h->dTmp;
@@ -891,6 +1010,9 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         } profile_off(h);
         const int keep_prof = profile_off.keep;
         // ---- how far do the spikes reach?  probe the first and last column of W and of V
+        // (twisted: the truncated interfaces sit at the chain-local TOP of every chain -- the natural V spike of a partition
+        //  is the flipped bottom half's W -- so only W is probed; the seam at the chains' bottoms is exact whatever the decay)
+        const int nwhich = tw ? 1 : 2;
         int m = 0;
         double *dStat = nullptr;  // [absmax_in, absmax_out, probe absmax, extent(int)]
         HIPCHK(tmp.alloc(&dStat, 4));
@@ -904,16 +1026,17 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         // and the backward sweep starts where the solution is already below the drop level.
         auto build_sub = [&](int nb, SubChains &top, SubChains &bot) -> int {
             const int R = cfg.R;
-            std::vector<ChainDesc> ct(P), cb(P);
+            std::vector<ChainDesc> ct(h->chainsV), cb(h->chainsV);   // factor space: identity vector map, flags kept
             std::vector<GroupDesc> gtF(P), gtB(P), gbF(P), gbB(P);
             for (int p = 0; p < P; ++p) {
-                const ChainDesc &c = h->chains[p];
+                const ChainDesc &c = h->chainsV[p];
                 const GroupDesc &g = h->groups[p];
                 const int skip = c.nsteps - nb;
                 ct[p].row0 = c.row0; ct[p].nrows = std::min<int>(c.nrows, nb * R); ct[p].nsteps = nb;
                 gtF[p] = g; gtF[p].maxsteps = nb;
                 gtB[p] = g; gtB[p].maxsteps = nb; gtB[p].tile0 = g.tile0 + skip;
                 cb[p].row0 = c.row0 + (int64_t)skip * R; cb[p].nrows = c.nrows - skip * R; cb[p].nsteps = nb;
+                ct[p].vec0 = ct[p].row0; cb[p].vec0 = cb[p].row0;
                 gbF[p] = g; gbF[p].maxsteps = nb; gbF[p].tile0 = g.tile0 + skip;
                 gbB[p] = g; gbB[p].maxsteps = nb;
             }
@@ -943,19 +1066,19 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (shallow && (rc = build_sub(nbp, pTop, pBot))) return rc;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 HIPCHK(hipMemsetAsync(dStat + 3, 0, sizeof(double), st));
-                for (int which = 0; which < 2; ++which) {
+                for (int which = 0; which < nwhich; ++which) {
                     HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
                     for (int t = 0; t < 2; ++t) {
                         const int col = t == 0 ? 0 : K - 1;
                         if (t == 1 && K == 1) break;
-                        HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhs, st));
+                        HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChainsV, P, which, col, rhs, st));
                         if (shallow) HIPCHK(hipMemsetAsync(sol, 0, sizeof(double) * n, st));   // rows outside the probed depth read as zero
                         if ((rc = run_pass(h, rhs, sol, false, shallow ? (which == 0 ? &pTop : &pBot) : nullptr))) return rc;
                         HIPCHK(launch_absmax_diag(sol, n, 0, n, dStat + 2, st));
                         double amax = 0.0;
                         HIPCHK(hipMemcpyAsync(&amax, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
                         HIPCHK(hipStreamSynchronize(st));
-                        HIPCHK(launch_spike_extent(sol, h->dChains, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
+                        HIPCHK(launch_spike_extent(sol, h->dChainsV, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
                     }
                 }
                 HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -968,33 +1091,32 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         mark("spike reach probe");
         if (h->S > 1) {
             // do the spikes die (below spike_tol of their peak) before they reach the far end of the shortest chain?
-            double bad = ((int64_t)(extent * 1.06) + K > nmin) ? 1.0 : 0.0;
-            if (exchanging(h)) {  // every rank must take the same decision (the redo below is collective)
-                HIPCHK(hipMemcpyAsync(dStat + 2, &bad, sizeof(double), hipMemcpyHostToDevice, st));
-                if ((rc = coll_allreduce(h, dStat + 2, 1, NCCL_MAX))) return rc;
-                HIPCHK(hipMemcpyAsync(&bad, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-            }
-            if (bad != 0.0) {
+            // (every rank must take the same decision: the redo is collective)
+            bool bad = (int64_t)(extent * 1.06) + K > nmin;
+            if ((rc = any_rank(bad, dStat + 2, &bad))) return rc;
+            if (bad) {
                 h->profile = keep_prof;
-                // the redo allocates its own LU scratch, probe vectors and descriptors: give this attempt's back first
-                // (otherwise two LU scratches + the band + the factors are alive at once on this path only)
-                HIPCHK(hipStreamSynchronize(st));
-                tmp.release_all();
-                return setup_impl(h, n_global, row0, n, K, band, ld, on_device, false);
+                // a caller-chosen P: one chain per partition, untwisted (the untwisted chains would be as long as these and
+                // fail the same test); the library's own P: the same chains untwisted -- nothing is promised about them
+                return h->opt_partitions > 0 ? redo(false, false) : redo(allow_subsplit, false);
             }
         }
         if (h->spike_storage) {
             m = (int)(((int64_t)(extent * 1.06) + 64 + 63) / 64 * 64);  // 2 probed columns -> small margin; verified below
             if (m > nmin) m = nmin;
             // worth it only while the correction stays well below a pass over the factors
-            const double corr_bytes = 2.0 * m * (double)K * 8.0 * P;
+            const double corr_bytes = (tw ? 1.0 : 2.0) * m * (double)K * 8.0 * P;
             const double pass_bytes = 2.0 * (double)h->factor_doubles * 8.0;
             if (corr_bytes > 0.85 * pass_bytes) m = 0;  // 1 + corr/pass passes against 2 for re-solving
         }
+        if (tw) {   // the twisted apply is the one-pass apply: without stored spikes there is nothing to gain
+            bool give_up = m == 0;
+            if ((rc = any_rank(give_up, dStat + 2, &give_up))) return rc;
+            if (give_up) { h->profile = keep_prof; return redo(allow_subsplit, false); }
+        }
         if (m > 0) {
             HIPCHK(dalloc(&h->dWf, (size_t)P * K * m));
-            HIPCHK(dalloc(&h->dVf, (size_t)P * K * m));
+            if (!tw) HIPCHK(dalloc(&h->dVf, (size_t)P * K * m));
         }
         // The spikes vanish beyond m rows, so the 2K solves only need the row blocks next to the interfaces:
         // the top nb blocks of every chain for W, the bottom nb blocks for V (exact on the forward sweep, and the
@@ -1009,19 +1131,30 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             }
         }
         mark("sub-chain descriptors");
+        // seam matrices of every chain (twisted): Tb = the forward-swept bottom coupling block, Gb = (D^-1 U)_bb^-1
+        double *dTb = nullptr, *dGb = nullptr;
+        if (tw) {
+            HIPCHK(tmp.alloc(&dTb, (size_t)P * kk));
+            HIPCHK(tmp.alloc(&dGb, (size_t)P * kk));
+            HIPCHK(hipMemsetAsync(dTb, 0, sizeof(double) * P * kk, st));
+            HIPCHK(hipMemsetAsync(dGb, 0, sizeof(double) * P * kk, st));
+        }
         // The 2K spike columns are solved sweep_multi_nr(cfg) at a time (k_sweep_multi: a factor tile is read once for the
         // whole batch) where the configuration has one chain per workgroup; narrow bands keep one column per pass.
         // Spike columns.  K > 32 with decayed spikes (partial) and chain lengths that are multiples of 16: all K
-        // columns at once by the blocked banded TRSM on MFMA over the dense LU tiles (k_spike_trsm); otherwise as
+        // columns at once by the blocked banded TRSM on MFMA over the dense LU tiles (k_spike_trsm2); otherwise as
         // right-hand sides of the sweep kernels, a few columns per pass over the packed factors.
-        bool trsm = partial && lu_blk != 0 && getenv("SPIKE_NO_TRSM") == nullptr;
+        // (twisted, K > 32: always the TRSM -- it also delivers the seam matrices; a region longer than a chain is clipped)
+        bool trsm = (partial || tw) && lu_blk != 0 && getenv("SPIKE_NO_TRSM") == nullptr;
         for (int p = 0; p < P && trsm; ++p) trsm = h->chains[p].nrows % 16 == 0;
+        if (tw && lu_blk != 0 && !trsm) return fail(h, SPIKE_ERR_STATE, "internal: twisted factorisation without the block TRSM");
         if (trsm) {
-            const int region = ((m + K + cfg.R - 1) / cfg.R + 1) * cfg.R;   // the same rows the sweep-based partial solves cover
+            int region = ((m + K + cfg.R - 1) / cfg.R + 1) * cfg.R;   // the same rows the sweep-based partial solves cover
+            if (region > (nmax + 63) / 64 * 64) region = (nmax + 63) / 64 * 64;
             double *dZ = nullptr;
             HIPCHK(tmp.alloc(&dZ, spike_trsm_scratch_doubles(K, P, region)));
-            HIPCHK(launch_spike_trsm(dLU, K, m, region, h->dChains, P, h->dA, h->ldA, n_global, row0, h->dWt, h->dVb, h->dWf, h->dVf,
-                                     dZ, dStat, dStat + 1, st));
+            HIPCHK(launch_spike_trsm(dLU, K, m, region, h->dChainsV, P, bandF, ldF, h->dWt, h->dVb, h->dWf, h->dVf,
+                                     dZ, dStat, dStat + 1, st, dTb, dGb, h->dDinv));
             HIPCHK(hipStreamSynchronize(st));
             tmp.release(dZ);
         }
@@ -1033,15 +1166,15 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(tmp.alloc(&solM, (size_t)NRB * n));
             HIPCHK(tmp.alloc(&midM, (size_t)NRB * n));
         }
-        for (int which = 0; which < 2 && !trsm; ++which) {
+        for (int which = 0; which < nwhich && !trsm; ++which) {
             HIPCHK(hipMemsetAsync(rhsM, 0, sizeof(double) * n * NRB, st));
             const SubChains *sub = partial ? (which == 0 ? &subTop : &subBot) : nullptr;
             for (int col = 0; col < K; col += NRB) {
                 const int nc = std::min(NRB, K - col);  // a short last batch solves stale columns too; they are not gathered
-                HIPCHK(launch_tip_rhs(h->dA, h->ldA, K, n_global, row0, h->dChains, P, which, col, rhsM, st, nc, n));
+                HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChainsV, P, which, col, rhsM, st, nc, n));
                 if (batched) {
                     SweepArgs a;
-                    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChains; a.nchains = P; a.K = K;
+                    a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChainsV; a.nchains = P; a.K = K;
                     a.tiles = h->dLt; a.in = rhsM; a.out = midM; a.dinv = h->dDinv; a.corr_top = a.corr_bot = nullptr;
                     HIPCHK(launch_sweep_multi(cfg, false, P, a, n, st));
                     a.tiles = h->dUt; a.in = midM; a.out = solM; a.dinv = nullptr;
@@ -1051,10 +1184,11 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                     rc = run_pass(h, rhsM, solM, false, sub);
                     if (rc) return rc;
                 }
-                HIPCHK(launch_tip_gather(solM, K, h->dChains, P, which, col, which == 0 ? h->dWt : h->dVb, st, nc, n));
-                if (m > 0) HIPCHK(launch_spike_gather(solM, K, m, h->dChains, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st, nc, n));
+                HIPCHK(launch_tip_gather(solM, K, h->dChainsV, P, which, col, which == 0 ? h->dWt : h->dVb, st, nc, n));
+                if (m > 0) HIPCHK(launch_spike_gather(solM, K, m, h->dChainsV, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st, nc, n));
             }
         }
+        if (tw && !lu_blk) HIPCHK(launch_seam_small(dLU, n, K, bandF, ldF, h->dChainsV, P, dTb, dGb, st));   // K <= 32: off the diagonal-major LU scratch
         if (batched && !trsm) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
         HIPCHK(hipStreamSynchronize(st));
         tmp.release(dLU);
@@ -1067,20 +1201,75 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             // anything of weight left at the far edge of the window?  then the spikes do not decay: keep the re-solve variant
             // (a window that covers every chain completely holds the full spikes: nothing to check)
             if (m < nmax && stat[1] > 1e3 * h->spike_tol * stat[0]) {
-                (void)hipFree(h->dWf); (void)hipFree(h->dVf);
+                (void)hipFree(h->dWf); if (h->dVf) (void)hipFree(h->dVf);
                 h->dWf = h->dVf = nullptr;
                 m = 0;
             }
         }
+        // ---- twisted: the seam systems.  With zeta = the corrected forward result at a chain's last K rows,
+        //   zeta_a + Tb_a J Gb_b zeta_b = y_a,   zeta_b + Tb_b J Gb_a zeta_a = y_b      (a = top half, b = bottom half, J = reversal)
+        // -- the shape of a SPIKE interface system (W = Tb_a J Gb_b, V = Tb_b J Gb_a, S = I - W V), so the interface kernels
+        // set it up and solve it, in place on the intermediate vector between the two sweep launches
+        if (tw) {
+            const int npairs = P / 2;
+            double *dWs = nullptr, *dVs = nullptr, *dWorkS = nullptr;
+            int *dFlagS = nullptr;
+            HIPCHK(tmp.alloc(&dWs, (size_t)npairs * kk));
+            HIPCHK(tmp.alloc(&dVs, (size_t)npairs * kk));
+            HIPCHK(tmp.alloc(&dWorkS, (size_t)npairs * 2 * kk));
+            HIPCHK(tmp.alloc(&dFlagS, (size_t)npairs));
+            HIPCHK(hipMemsetAsync(dFlagS, 0, sizeof(int) * npairs, st));
+            HIPCHK(dalloc(&h->dSeamWT, (size_t)npairs * kk));
+            HIPCHK(dalloc(&h->dSeamVT, (size_t)npairs * kk));
+            HIPCHK(dalloc(&h->dSeamST, (size_t)npairs * kk));
+            HIPCHK(launch_seam_products(K, npairs, dTb, dGb, dWs, dVs, st));
+            HIPCHK(launch_iface_setup(K, npairs, dWs, dVs, h->dSeamWT, h->dSeamVT, h->dSeamST, dWorkS, dFlagS, st));
+            std::vector<int> sflags(npairs, 0);
+            HIPCHK(hipMemcpyAsync(sflags.data(), dFlagS, sizeof(int) * npairs, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            tmp.release(dWorkS); tmp.release(dWs); tmp.release(dVs); tmp.release(dTb); tmp.release(dGb);
+            // a singular seam (the diagonal block itself is singular to working precision) or spikes that turned out not to
+            // decay: start over with ordinary chains (collective)
+            bool give_up = m == 0;
+            for (int t = 0; t < npairs; ++t) give_up = give_up || sflags[t] != 0;
+            if ((rc = any_rank(give_up, dStat + 2, &give_up))) return rc;
+            if (give_up) return redo(allow_subsplit, false);
+            std::vector<IfaceDesc> sm(npairs);
+            for (int t = 0; t < npairs; ++t) {
+                const ChainDesc &ca = h->chainsV[2 * t], &cb = h->chainsV[2 * t + 1];
+                IfaceDesc &d = sm[t];
+                d.gt = nullptr; d.gt_off = ca.row0 + ca.nrows - K;   // "t" = the top half a, "b" = the bottom half b
+                d.gb = nullptr; d.gb_off = cb.row0 + cb.nrows - K;   // (factor space: offsets into the intermediate vector)
+                d.WT = h->dSeamWT + (size_t)t * kk; d.ST = h->dSeamST + (size_t)t * kk; d.VT = h->dSeamVT + (size_t)t * kk;
+                d.BT = d.CT = nullptr; d.corr_bot = d.corr_top = nullptr;
+                d.xt_out = h->dY + d.gt_off; d.xb_out = h->dY + d.gb_off;
+            }
+            HIPCHK(dalloc(&h->dIfsSeam, (size_t)npairs));
+            HIPCHK(upload(h, h->dIfsSeam, sm.data(), sizeof(IfaceDesc) * npairs, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->nseam = npairs;
+            mark("seam systems");
+        }
         h->spike_m = m;
         HIPCHK(hipStreamSynchronize(st));
         tmp.release(sol);
-        HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 0, h->dCT, st));
-        HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, n_global, row0, h->dChains, P, 1, h->dBT, st));
+        if (!tw) {
+            HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, h->dChains, P, 0, h->dCT, st));
+            HIPCHK(launch_coupling_blocks(h->dA, h->ldA, K, h->dChains, P, 1, h->dBT, st));
+        }
 
-        // interface i (local numbering): upper chain = i, lower chain = i+1; rank boundaries appended
+        // interface i (local numbering) lies between chain cu(i) above and chain cl(i) below it; rank boundaries appended.
+        // Ordinary chains: cu = i, cl = i + 1.  Twisted: between pair i and pair i + 1, i.e. cu = 2i + 1 (a bottom half, whose
+        // chain-local TOP is the partition's last row: the natural V tip is its W tip with rows and columns reversed) and
+        // cl = 2i + 2 (a top half).
+        auto cu = [&](int i) { return tw ? 2 * i + 1 : i; };
+        auto cl = [&](int i) { return tw ? 2 * i + 2 : i + 1; };
+        // vector-space offset of the K rows at the partition end a chain represents
+        auto bot_tip_off = [&](int c) { const ChainDesc &q = h->chains[c]; return q.vdir > 0 ? q.vec0 + q.nrows - K : q.vec0 - K + 1; };
+        auto top_tip_off = [&](int c) { return h->chains[c].vec0; };
         double *dWif = nullptr, *dVif = nullptr, *dWork = nullptr;
         int *dFlag = nullptr;
+        if (nif > 0) {
         HIPCHK(tmp.alloc(&dWif, (size_t)nif * kk));
         HIPCHK(tmp.alloc(&dVif, (size_t)nif * kk));
         HIPCHK(tmp.alloc(&dWork, (size_t)nif * 2 * kk));
@@ -1089,18 +1278,26 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(dalloc(&h->dWT, (size_t)nif * kk));
         HIPCHK(dalloc(&h->dVT, (size_t)nif * kk));
         HIPCHK(dalloc(&h->dST, (size_t)nif * kk));
-        // local interfaces: W of chain i+1, V of chain i
+        }
+        // local interfaces: W of chain cl(i), V of chain cu(i)
         if (nif_local > 0) {
-            HIPCHK(hipMemcpyAsync(dWif, h->dWt + kk, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(dVif, h->dVb, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
+            if (tw) {
+                HIPCHK(hipMemcpy2DAsync(dWif, kk * sizeof(double), h->dWt + 2 * kk, 2 * kk * sizeof(double), kk * sizeof(double), nif_local,
+                                        hipMemcpyDeviceToDevice, st));
+                HIPCHK(launch_flip_kk(K, nif_local, h->dWt, 1, 2, dVif, st));
+            } else {
+                HIPCHK(hipMemcpyAsync(dWif, h->dWt + kk, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(dVif, h->dVb, sizeof(double) * nif_local * kk, hipMemcpyDeviceToDevice, st));
+            }
         }
         int ib_prev = -1, ib_next = -1;
         if (multi) {
-            // exchange [W_first | V_last] of every rank
+            // exchange [W_first | V_last] of every rank (natural orientation)
             HIPCHK(dalloc(&h->dSend, 2 * kk > (size_t)2 * K ? 2 * kk : (size_t)2 * K));
             HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * (2 * kk > (size_t)2 * K ? 2 * kk : (size_t)2 * K)));
             HIPCHK(hipMemcpyAsync(h->dSend, h->dWt, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(h->dSend + kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+            if (tw) HIPCHK(launch_flip_kk(K, 1, h->dWt, P - 1, 1, h->dSend + kk, st));
+            else HIPCHK(hipMemcpyAsync(h->dSend + kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
             if ((rc = coll_allgather(h, h->dSend, h->dRecv, 2 * kk))) return rc;
             int idx = nif_local;
             if (h->rank > 0) {  // interface with the previous rank: V = prev rank's V_last, W = my W_first
@@ -1111,15 +1308,17 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (h->rank < h->nranks - 1) {  // interface with the next rank: V = my V_last, W = next rank's W_first
                 ib_next = idx++;
                 HIPCHK(hipMemcpyAsync(dWif + (size_t)ib_next * kk, h->dRecv + (size_t)(h->rank + 1) * 2 * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(dVif + (size_t)ib_next * kk, h->dVb + (size_t)(P - 1) * kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(dVif + (size_t)ib_next * kk, h->dSend + kk, sizeof(double) * kk, hipMemcpyDeviceToDevice, st));
             }
         }
         mark("coupling blocks + exchange");
-        HIPCHK(launch_iface_setup(K, nif, dWif, dVif, h->dWT, h->dVT, h->dST, dWork, dFlag, st));
-        std::vector<int> flags(nif, 0);
-        HIPCHK(hipMemcpyAsync(flags.data(), dFlag, sizeof(int) * nif, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        tmp.release(dWork);
+        std::vector<int> flags(nif > 0 ? nif : 0, 0);
+        if (nif > 0) {
+            HIPCHK(launch_iface_setup(K, nif, dWif, dVif, h->dWT, h->dVT, h->dST, dWork, dFlag, st));
+            HIPCHK(hipMemcpyAsync(flags.data(), dFlag, sizeof(int) * nif, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            tmp.release(dWork);
+        }
         for (int i = 0; i < nif; ++i)
             if (flags[i]) return fail(h, SPIKE_ERR_SINGULAR, "interface system %d is singular", i);
 
@@ -1127,37 +1326,40 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         std::vector<IfaceDesc> ifs(nif);
         for (int i = 0; i < nif_local; ++i) {
             IfaceDesc &d = ifs[i];
-            d.gb = nullptr; d.gb_off = h->chains[i].row0 + h->chains[i].nrows - K;  // read in place from the swept vector
-            d.gt = nullptr; d.gt_off = h->chains[i + 1].row0;
+            d.gb = nullptr; d.gb_off = bot_tip_off(cu(i));  // read in place from the swept vector
+            d.gt = nullptr; d.gt_off = top_tip_off(cl(i));
             d.WT = h->dWT + (size_t)i * kk; d.ST = h->dST + (size_t)i * kk; d.VT = h->dVT + (size_t)i * kk;
-            d.BT = h->dBT + (size_t)i * kk; d.CT = h->dCT + (size_t)(i + 1) * kk;
-            d.corr_bot = h->dCorrBot + (size_t)i * K;
-            d.corr_top = h->dCorrTop + (size_t)(i + 1) * K;
+            d.BT = tw ? nullptr : h->dBT + (size_t)i * kk; d.CT = tw ? nullptr : h->dCT + (size_t)(i + 1) * kk;
+            d.corr_bot = tw ? nullptr : h->dCorrBot + (size_t)i * K;
+            d.corr_top = tw ? nullptr : h->dCorrTop + (size_t)(i + 1) * K;
         }
         if (ib_prev >= 0) {
             IfaceDesc &d = ifs[ib_prev];
             d.gb = h->dRecv + ((size_t)(h->rank - 1) * 2 + 1) * K;  // previous rank's gb_last (apply-time layout: 2K per rank)
-            d.gt = nullptr; d.gt_off = h->chains[0].row0; d.gb_off = 0;
+            d.gt = nullptr; d.gt_off = top_tip_off(0); d.gb_off = 0;
             d.WT = h->dWT + (size_t)ib_prev * kk; d.ST = h->dST + (size_t)ib_prev * kk; d.VT = h->dVT + (size_t)ib_prev * kk;
-            d.BT = nullptr; d.CT = h->dCT;
-            d.corr_bot = nullptr; d.corr_top = h->dCorrTop;
+            d.BT = nullptr; d.CT = tw ? nullptr : h->dCT;
+            d.corr_bot = nullptr; d.corr_top = tw ? nullptr : h->dCorrTop;
         }
         if (ib_next >= 0) {
             IfaceDesc &d = ifs[ib_next];
-            d.gb = nullptr; d.gb_off = h->chains[P - 1].row0 + h->chains[P - 1].nrows - K; d.gt_off = 0;
+            d.gb = nullptr; d.gb_off = bot_tip_off(P - 1); d.gt_off = 0;
             d.gt = h->dRecv + ((size_t)(h->rank + 1) * 2) * K;  // next rank's gt_first
             d.WT = h->dWT + (size_t)ib_next * kk; d.ST = h->dST + (size_t)ib_next * kk; d.VT = h->dVT + (size_t)ib_next * kk;
-            d.BT = h->dBT + (size_t)(P - 1) * kk; d.CT = nullptr;
-            d.corr_bot = h->dCorrBot + (size_t)(P - 1) * K; d.corr_top = nullptr;
+            d.BT = tw ? nullptr : h->dBT + (size_t)(P - 1) * kk; d.CT = nullptr;
+            d.corr_bot = tw ? nullptr : h->dCorrBot + (size_t)(P - 1) * K; d.corr_top = nullptr;
         }
         for (auto &d : ifs) { d.xb_out = nullptr; d.xt_out = nullptr; }
-        HIPCHK(dalloc(&h->dIfs, (size_t)nif));
-        HIPCHK(upload(h, h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, st));
+        if (nif > 0) {
+            HIPCHK(dalloc(&h->dIfs, (size_t)nif));
+            HIPCHK(upload(h, h->dIfs, ifs.data(), sizeof(IfaceDesc) * nif, st));
+        }
         // cuts inside a caller partition stay coupled even in the decoupled (block-Jacobi) variant
         std::vector<int> internal;
-        if (h->S > 1)
+        const int per_part = tw ? h->S / 2 : h->S;   // chains (pairs) per caller partition
+        if (per_part > 1)
             for (int i = 0; i < nif_local; ++i)
-                if ((i + 1) % h->S != 0) internal.push_back(i);
+                if ((i + 1) % per_part != 0) internal.push_back(i);
         h->nif_int = (int)internal.size();
         if (h->nif_int > 0) {
             std::vector<IfaceDesc> ii;
@@ -1167,9 +1369,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(hipStreamSynchronize(st));
         }
         h->nif_local_all = nif_local;
-        if (h->spike_m > 0 && K >= 1 && K <= 8 && !multi) HIPCHK(dalloc(&h->dTips1, (size_t)2 * P * K));   // k_couple_small
+        if (h->spike_m > 0 && K >= 1 && K <= 8 && !multi && !tw) HIPCHK(dalloc(&h->dTips1, (size_t)2 * P * K));   // k_couple_small
         if (h->spike_m > 0) {
             // one-pass variant: the interface kernel only has to deliver the tip solutions
+            // (slot c + 1 of dXb / dXt = the tip solution at the partition end chain c represents)
             HIPCHK(dalloc(&h->dXb, (size_t)(P + 2) * K));
             HIPCHK(dalloc(&h->dXt, (size_t)(P + 2) * K));
             HIPCHK(hipMemsetAsync(h->dXb, 0, sizeof(double) * (P + 2) * K, st));
@@ -1177,13 +1380,15 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             std::vector<IfaceDesc> ff(ifs);
             for (auto &d : ff) { d.BT = d.CT = nullptr; d.corr_bot = d.corr_top = nullptr; }
             for (int i = 0; i < nif_local; ++i) {
-                ff[i].xb_out = h->dXb + (size_t)(i + 1) * K;  // bottom tip of chain i
-                ff[i].xt_out = h->dXt + (size_t)(i + 2) * K;  // top tip of chain i+1
+                ff[i].xb_out = h->dXb + (size_t)(cu(i) + 1) * K;  // bottom tip of the partition above
+                ff[i].xt_out = h->dXt + (size_t)(cl(i) + 1) * K;  // top tip of the partition below
             }
             if (ib_prev >= 0) { ff[ib_prev].xb_out = h->dXb; ff[ib_prev].xt_out = h->dXt + (size_t)K; }
             if (ib_next >= 0) { ff[ib_next].xb_out = h->dXb + (size_t)P * K; ff[ib_next].xt_out = h->dXt + (size_t)(P + 1) * K; }
-            HIPCHK(dalloc(&h->dIfsFast, (size_t)nif));
-            HIPCHK(upload(h, h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, st));
+            if (nif > 0) {
+                HIPCHK(dalloc(&h->dIfsFast, (size_t)nif));
+                HIPCHK(upload(h, h->dIfsFast, ff.data(), sizeof(IfaceDesc) * nif, st));
+            }
             if (h->nif_int > 0) {
                 std::vector<IfaceDesc> fi;
                 for (int i : internal) fi.push_back(ff[i]);
@@ -1222,15 +1427,16 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     const int nif = coupled ? h->nif : h->nif_int;  // decoupled: only the cuts inside the caller's partitions
     const bool multi = coupled && nif > 0 && exchanging(h);
     const int K = h->K, P = h->P;
-    if ((rc = run_pass(h, x, y, false))) return rc;
+    if ((rc = run_pass(h, x, y, false))) return rc;   // (twisted: includes the seam solves between the two launches)
     if (nif <= 0) return SPIKE_OK;
     // interfaces: [0, nloc) lie between two chains of this rank, [nloc, nif) are shared with the neighbouring ranks and
     // need the exchanged tips ([g_top(first chain) | g_bottom(last chain)] = the first and last K entries of y)
-    const int nloc = multi ? P - 1 : nif, nedge = nif - nloc;
+    const int nloc = multi ? h->nif_local_all : nif, nedge = nif - nloc;
     const IfaceDesc *ifs = h->spike_m > 0 ? (coupled ? h->dIfsFast : h->dIfsFastInt) : (coupled ? h->dIfs : h->dIfsInt);
     // (with spike windows that overlap inside a chain a correction of one chain end can reach the other end's tip rows,
     //  which the exchange stream still reads: serial order then)
-    const bool overlap = multi && h->overlap && (h->spike_m == 0 || 2 * h->spike_m <= h->min_chain_rows);
+    // (twisted: a chain has one window, at its own top, never longer than the chain: no such reach)
+    const bool overlap = multi && h->overlap && (h->spike_m == 0 || h->twisted || 2 * h->spike_m <= h->min_chain_rows);
     hipStream_t sx = st;   // stream of the exchange and of the work that depends on it
     if (overlap) {
         // The exchange is needed by the (at most two) rank-boundary interfaces and by the corrections they drive -- the
@@ -1265,20 +1471,20 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     // windows and the general kernels are as fast), one rank, every interface coupled, windows that do not overlap: the small
     // coupling step (two tiny launches)
     if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
-        h->nif_local_all == P - 1)
+        h->nif_local_all == P - 1 && !h->twisted)
         return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
                    ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
-        HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0));
+        HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0, h->twisted));
     if (multi) {
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, sx, y, h->n, K, h->dSend);
         HIPCHK(hipGetLastError());
         if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K, sx))) return rc;
         HIPCHK(launch_iface_apply(K, nedge, ifs + nloc, y, sx));
         if (h->spike_m > 0)
-            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2));
+            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2, h->twisted));
         if (overlap) {
             HIPCHK(hipEventRecord(h->evJoin, sx));
             HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));
@@ -1741,10 +1947,10 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
     o->nboost = h->nboost;
     o->factor_bytes = (int64_t)(2 * h->factor_doubles + (size_t)h->n) * 8;
-    o->iface_bytes = (int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) * (int64_t)h->K * h->K * 8;
+    o->iface_bytes = ((int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) + (int64_t)h->nseam * 3) * (int64_t)h->K * h->K * 8;
     o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;
-    o->spike_bytes = (int64_t)2 * h->spike_m * (int64_t)h->K * 8 * h->P;
+    o->spike_bytes = (int64_t)(h->twisted ? 1 : 2) * h->spike_m * (int64_t)h->K * 8 * h->P;
     o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
     return SPIKE_OK;
 }
@@ -1754,10 +1960,10 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
     if (!h || !buf || !len) return SPIKE_ERR_ARG;
     snprintf(buf, len,
              "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
-             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d, chains = %d\n",
+             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d, chains = %d%s\n",
              (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P_user,
              h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
-             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->P);
+             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->P, h->twisted ? " (twisted pairs)" : "");
     return SPIKE_OK;
 }
 
@@ -1770,7 +1976,13 @@ extern "C" int spike_get_tips(spike_handle h, double *Vb, double *Wt)
     // interface i of the caller's partitioning: V of the last chain of partition i, W of the first chain of i+1
     for (int i = 0; i < h->P_user - 1; ++i) {
         const size_t cv = (size_t)(i + 1) * h->S - 1, cw = (size_t)(i + 1) * h->S;
-        HIPCHK(hipMemcpy(Vb + (size_t)i * kk, h->dVb + cv * kk, sizeof(double) * kk, hipMemcpyDeviceToHost));
+        // twisted: the last chain of a partition is a bottom half stored flipped -- its W tip is the natural V tip with rows
+        // and columns reversed
+        HIPCHK(hipMemcpy(Vb + (size_t)i * kk, (h->twisted ? h->dWt : h->dVb) + cv * kk, sizeof(double) * kk, hipMemcpyDeviceToHost));
+        if (h->twisted) {
+            double *v = Vb + (size_t)i * kk;
+            for (size_t t = 0; t < kk / 2; ++t) { const double q = v[t]; v[t] = v[kk - 1 - t]; v[kk - 1 - t] = q; }
+        }
         HIPCHK(hipMemcpy(Wt + (size_t)i * kk, h->dWt + cw * kk, sizeof(double) * kk, hipMemcpyDeviceToHost));
     }
     return SPIKE_OK;

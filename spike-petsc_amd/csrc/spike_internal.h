@@ -8,12 +8,25 @@ namespace spike {
 
 constexpr int BLK = 64;  // partition boundaries fall on multiples of 64 rows
 
-// One SPIKE partition = one chain of row blocks swept sequentially.
+// One chain of row blocks swept sequentially by one workgroup (a SPIKE partition, a sub-chain of one, or -- twisted
+// factorisation -- one HALF of a partition).
+//
+// Two index spaces.  FACTOR space ("virtual rows"): where the chain's matrix rows live in the LU scratch, the packed tiles,
+// 1/diag, the intermediate vector of an apply and every setup-time vector: rows row0 .. row0 + nrows - 1, chain-local row r
+// at row0 + r.  VECTOR space: where chain-local row r lives in the caller's vectors x and y: vec0 + vdir * r.  For an
+// ordinary chain the two coincide (vec0 = row0, vdir = +1).  The BOTTOM half of a twisted partition is factored from the
+// partition's last row upward: its chain-local row 0 is the partition's last row (vec0 = that row, vdir = -1) and its band is
+// stored flipped (rows and diagonals reversed), so that factorisation, packing and the spike solves see an ordinary chain
+// whose first row is the partition's OUTER end and whose last row is the seam in the middle of the partition.
 struct ChainDesc {
-    int64_t row0;    // first local row
-    int32_t nrows;   // rows in the partition
+    int64_t row0;    // first row in factor space
+    int32_t nrows;   // rows of the chain
     int32_t nsteps;  // ceil(nrows / R)
+    int64_t vec0;    // vector index of chain-local row 0
+    int32_t vdir;    // +1 | -1
+    int32_t flags;   // CHAIN_HAS_TOP | CHAIN_HAS_BOT: a coupling block exists above the first / below the last chain-local row
 };
+constexpr int CHAIN_HAS_TOP = 1, CHAIN_HAS_BOT = 2;
 
 // One workgroup = NW waves sweeping CPW = 64/R chains in lock-step.
 struct GroupDesc {
@@ -102,14 +115,13 @@ hipError_t launch_band_to_tiles(int64_t n, int K, const double *band, int64_t ld
 hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const double *xh, double *y, hipStream_t st);
 // tips: rhs[row0+a] = block(a,b) for every chain (which: 0 = C at top rows of chains with has_top,
 // 1 = B at bottom rows of chains with has_bot); gather copies K rows of sol into column b of out.
-hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st,
-                          int ncols = 1, int64_t ldr = 0);
+hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, const ChainDesc *chains, int nchains, int which, int col,
+                          double *rhs, hipStream_t st, int ncols = 1, int64_t ldr = 0);
 hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, int nchains, int which, int col,
                              double *out, hipStream_t st, int ncols = 1, int64_t ldr = 0);
 // coupling blocks B (which=1) / C (which=0) of every chain as dense column-major K x K
-hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                                  const ChainDesc *chains, int nchains, int which, double *out, hipStream_t st);
+hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, const ChainDesc *chains, int nchains, int which,
+                                  double *out, hipStream_t st);
 // S = I - W V, inverse by Gauss-Jordan with partial pivoting; W,V row-major K x K per interface in;
 // outputs column-major WT, VT, ST.  flag[i] != 0 when interface i is singular.
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
@@ -124,16 +136,33 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
                                int *extent, hipStream_t st);
 hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
                                const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st);
+// twisted: every chain has ONE window, at its chain-local top (Wf); a vdir = -1 chain takes the next partition's x_t, reversed
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0);
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0, bool twisted = false);
+
+// twisted factorisation (setup): dst = the band in factor space (the rows of a vdir = -1 chain reversed, its diagonals mirrored)
+hipError_t launch_band_flip(const double *src, int64_t lds, int K, const ChainDesc *chains, int nchains, int max_rows,
+                            double *dst, int64_t ldd, hipStream_t st);
+// K x K matrices of every chain's SEAM end (its last K rows), row-major per chain: Tb = (D^-1 L^-1)_bb B (the forward-swept
+// bottom coupling block), Gb = (D^-1 U)_bb^-1.  launch_seam_small: K <= 32, from the diagonal-major LU scratch;
+// wider bands get them from launch_spike_trsm (Tb / Gb arguments).
+hipError_t launch_seam_small(const double *lu, int64_t ld, int K, const double *band, int64_t ldb, const ChainDesc *chains,
+                             int nchains, double *Tb, double *Gb, hipStream_t st);
+// per pair (chains 2t, 2t+1): W[t] = Tb[2t] J Gb[2t+1], V[t] = Tb[2t+1] J Gb[2t]  (J = reversal; row-major K x K)
+hipError_t launch_seam_products(int K, int npairs, const double *Tb, const double *Gb, double *W, double *V, hipStream_t st);
+// out[i] = J in[first + i stride] J for i < count (K x K row-major matrices; J = reversal of rows / columns)
+hipError_t launch_flip_kk(int K, int count, const double *in, int first, int stride, double *out, hipStream_t st);
 
 // spike columns by the blocked banded TRSM on MFMA (32 < K <= 128, chain lengths multiples of 16): reads the block-band LU
 // scratch `lu` (after launch_factor), fills the tips Wt / Vb, the stored spikes Wf / Vf (m rows, may be null with m = 0) and
 // the two extrema the caller checks the decay with; region = rows solved next to every interface (multiple of 64)
 size_t spike_trsm_scratch_doubles(int K, int nchains, int region);
+// Tb / Gb != nullptr (twisted factorisation): side 1 stops after its forward sweep and delivers Tb instead of Vb / Vf, a
+// third side solves (D^-1 U) X = [0; I] on the last K rows and delivers Gb (dinv = 1 / U_ii in factor space)
 hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
-                             int64_t ld, int64_t n_global, int64_t grow0, double *Wt, double *Vb, double *Wf, double *Vf,
-                             double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st);
+                             int64_t ld, double *Wt, double *Vb, double *Wf, double *Vf,
+                             double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st,
+                             double *Tb = nullptr, double *Gb = nullptr, const double *dinv = nullptr);
 hipError_t launch_read_bw(const double *src, int64_t ndoubles, double *sink, hipStream_t st);
 
 // Krylov pieces (spike_krylov.hip)

@@ -100,9 +100,15 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     const int p = grp * CPW + c;
     const bool valid = p < a.nchains;
     ChainDesc cd;
-    cd.row0 = 0; cd.nrows = 0; cd.nsteps = 0;
+    cd.row0 = 0; cd.nrows = 0; cd.nsteps = 0; cd.vec0 = 0; cd.vdir = 1; cd.flags = 0;
     if (valid) cd = a.chains[p];
     const GroupDesc gd = a.groups[grp];
+    // The caller's vectors live in VECTOR space (chain-local row r at vec0 + vdir r: the bottom half of a twisted partition
+    // runs through them backwards -- consecutive lanes still touch consecutive addresses), 1/diag and the intermediate
+    // vector between the two launches in FACTOR space (row0 + r): the forward launch reads x mapped and writes factor
+    // space, the backward launch reads factor space and writes y mapped.  Ordinary chains: the two spaces coincide.
+    const int64_t in0 = REV ? cd.row0 : cd.vec0, out0 = REV ? cd.vec0 : cd.row0;
+    const int64_t ind = REV ? 1 : cd.vdir, outd = REV ? cd.vdir : 1;
 
     for (int t = threadIdx.x; t < CPW * 2 * WS; t += NW * 64) (&W[0][0])[t] = 0.0;
     for (int t = threadIdx.x; t < CPW * (KP + R); t += NW * 64) (&W2[0][0])[t] = 0.0;
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
     auto issue = [&](Bundle &q, int s) {
         const int rl = row_of(s);
         const bool act = valid && s < cd.nsteps && rl >= 0 && rl < cd.nrows;
-        const int64_t gi = cd.row0 + (act ? rl : 0);        // clamped: the load is unconditional, the value selected later
-        q.fv = a.in[gi];
-        if (!REV) q.dv = a.dinv[gi];
+        const int rc = act ? rl : 0;                        // clamped: the load is unconditional, the value selected later
+        q.fv = a.in[in0 + ind * rc];
+        if (!REV) q.dv = a.dinv[cd.row0 + rc];
         const d2 *src = tp + (int64_t)s * TILE2;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) q.t[i] = __builtin_nontemporal_load(src + i * 64);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         const bool actc = valid && s < cd.nsteps;
         const int rl = row_of(s);
         const bool act = actc && rl < cd.nrows;
-        const int64_t gi = cd.row0 + rl;
+        const int64_t gi = out0 + outd * rl;
         double fv = act ? q.fv : 0.0;
         double dv = 1.0;
         if (!REV) {
@@ -2383,14 +2389,13 @@ hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const do
 // ---- spike tips by K pairs of sweeps (setup) -------------------------------------------------
 // C_p(a,b) = A[s+a, s-K+b]  -> band slot d = b - a        (a <= b)
 // B_p(a,b) = A[e-K+a, e+b]  -> band slot d = 2K + b - a   (b <= a)
-__device__ __forceinline__ bool has_top(const ChainDesc &cd, int64_t grow0) { return grow0 + cd.row0 > 0; }
-__device__ __forceinline__ bool has_bot(const ChainDesc &cd, int64_t grow0, int64_t n_global)
-{
-    return grow0 + cd.row0 + cd.nrows < n_global;
-}
+// (whether a chain end has a neighbour is the host's knowledge: ChainDesc::flags -- for the bottom half of a twisted
+//  partition "top" is the partition's LAST row and "bottom" the seam, see spike_internal.h)
+__device__ __forceinline__ bool has_top(const ChainDesc &cd) { return (cd.flags & CHAIN_HAS_TOP) != 0; }
+__device__ __forceinline__ bool has_bot(const ChainDesc &cd) { return (cd.flags & CHAIN_HAS_BOT) != 0; }
 
-__global__ void k_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, int64_t ldr)
+__global__ void k_tip_rhs(const double *band, int64_t ld, int K, const ChainDesc *chains, int nchains, int which, int col,
+                          double *rhs, int64_t ldr)
 {
     const int p = blockIdx.x;
     const ChainDesc cd = chains[p];
@@ -2398,24 +2403,22 @@ __global__ void k_tip_rhs(const double *band, int64_t ld, int K, int64_t n_globa
     rhs += blockIdx.y * ldr;
     for (int a = threadIdx.x; a < K; a += blockDim.x) {
         if (which == 0) {
-            if (!has_top(cd, grow0)) continue;
+            if (!has_top(cd)) continue;
             const int64_t r = cd.row0 + a;
             rhs[r] = (a <= col) ? band[(int64_t)(col - a) * ld + r] : 0.0;
         } else {
-            if (!has_bot(cd, grow0, n_global)) continue;
+            if (!has_bot(cd)) continue;
             const int64_t r = cd.row0 + cd.nrows - K + a;
             rhs[r] = (col <= a) ? band[(int64_t)(2 * K + col - a) * ld + r] : 0.0;
         }
     }
 }
 
-hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                          const ChainDesc *chains, int nchains, int which, int col, double *rhs, hipStream_t st, int ncols,
-                          int64_t ldr)
+hipError_t launch_tip_rhs(const double *band, int64_t ld, int K, const ChainDesc *chains, int nchains, int which, int col,
+                          double *rhs, hipStream_t st, int ncols, int64_t ldr)
 {
     if (nchains <= 0 || K <= 0 || ncols <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tip_rhs, dim3(nchains, ncols), dim3(64), 0, st, band, ld, K, n_global, grow0, chains, nchains, which,
-                       col, rhs, ldr);
+    hipLaunchKernelGGL(k_tip_rhs, dim3(nchains, ncols), dim3(64), 0, st, band, ld, K, chains, nchains, which, col, rhs, ldr);
     return hipGetLastError();
 }
 
@@ -2439,12 +2442,11 @@ hipError_t launch_tip_gather(const double *sol, int K, const ChainDesc *chains, 
     return hipGetLastError();
 }
 
-__global__ void k_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                                  const ChainDesc *chains, int which, double *out)
+__global__ void k_coupling_blocks(const double *band, int64_t ld, int K, const ChainDesc *chains, int which, double *out)
 {
     const int p = blockIdx.x;
     const ChainDesc cd = chains[p];
-    const bool on = which == 0 ? has_top(cd, grow0) : has_bot(cd, grow0, n_global);
+    const bool on = which == 0 ? has_top(cd) : has_bot(cd);
     for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
         const int a = t % K, b = t / K;  // column-major: out[b*K + a]
         double v = 0.0;
@@ -2456,12 +2458,11 @@ __global__ void k_coupling_blocks(const double *band, int64_t ld, int K, int64_t
     }
 }
 
-hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, int64_t n_global, int64_t grow0,
-                                  const ChainDesc *chains, int nchains, int which, double *out, hipStream_t st)
+hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, const ChainDesc *chains, int nchains, int which,
+                                  double *out, hipStream_t st)
 {
     if (nchains <= 0 || K <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_coupling_blocks, dim3(nchains), dim3(256), 0, st, band, ld, K, n_global, grow0, chains, which,
-                       out);
+    hipLaunchKernelGGL(k_coupling_blocks, dim3(nchains), dim3(256), 0, st, band, ld, K, chains, which, out);
     return hipGetLastError();
 }
 
@@ -2487,199 +2488,22 @@ __device__ __forceinline__ void atomic_max_pos(double *addr, double v);
 struct TrsmArgs {
     LuView lv;
     const ChainDesc *chains;
-    const double *band;      // kept band (diagonal-major): coupling blocks C, B for the right-hand sides
-    int64_t ld, n_global, grow0;
+    const double *band;      // band in factor space (diagonal-major): coupling blocks C, B for the right-hand sides
+    int64_t ld;
     int K, m, region;        // region = rows solved next to the interface (multiple of 64)
     double *Wt, *Vb;         // tips, row-major K x K per chain
     double *Wf, *Vf;         // stored spikes, column-major K x m per chain (may be null when m == 0)
     double *zscratch;        // per (chain, side, wave): region/16 tiles of 256 doubles
     double *absmax_in, *absmax_edge;
+    double *Tb, *Gb;         // twisted factorisation (else null): seam matrices, row-major K x K per chain (spike_internal.h)
+    const double *dinv;      // 1 / U_ii in factor space (the sweeps work with D^-1 L^-1 and D^-1 U, this solve with L and U)
 };
 
-template <int KB>
-__global__ __launch_bounds__(512) void k_spike_trsm(TrsmArgs a)
-{
-    constexpr int TL = 17;                       // LDS tile row stride
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwv = blockDim.x >> 6;
-    const int wg = w + nwv * blockIdx.z;         // column tile of this wave (K > 128: two workgroups of 8 waves share a chain side)
-    const int ncw = nwv * gridDim.z;
-    double *tb = lds + w * 2 * 16 * TL;          // this wave's working tile [row][col]
-    double *dt = tb + 16 * TL;                   // the diagonal factor tile
-    const int p = blockIdx.x, side = blockIdx.y;
-    const ChainDesc cd = a.chains[p];
-    const int K = a.K, m = a.m;
-    const int np = cd.nrows;
-    const bool on = side == 0 ? (a.grow0 + cd.row0 > 0) : (a.grow0 + cd.row0 + np < a.n_global);
-    const int c0 = 16 * wg;                      // this wave's columns c0 .. c0+15
-    double *tips = (side == 0 ? a.Wt : a.Vb) + (int64_t)p * K * K;
-    if (!on) {                                   // no neighbour on this side: the tips stay zero (setup cleared them)
-        return;
-    }
-    const int region = a.region < np ? a.region : np;
-    const int NB = region / 16;
-    const int rb0 = side == 0 ? 0 : (np - region) / 16;        // first row block of the region (chain-local)
-    const int rbs = side == 0 ? 0 : (np - K) / 16 - rb0;       // first region block with a nonzero right-hand side
-    const int64_t rbg0 = (cd.row0 >> 4) + rb0;
-    const LuView lv = a.lv;
-    double *zs = a.zscratch + (((int64_t)p * 2 + side) * ncw + wg) * (int64_t)NB * 256;
-    const int li = lane & 15, lk = lane >> 4;
-    typedef double v4 __attribute__((ext_vector_type(4)));
-    auto tile_ptr = [&](int rb, int slot) -> const double * { return lv.p + ((rbg0 + rb) * lv.ntl + slot) * 256; };
-
-    v4 Xw[KB];
-#pragma unroll
-    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
-
-    // right-hand side tile of region block rb in D layout (row = lk + 4r, col = li)
-    auto rhs_tile = [&](int rb) -> v4 {
-        v4 t = {0.0, 0.0, 0.0, 0.0};
-        const int col = c0 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = (rb0 + rb) * 16 + lk + 4 * r;       // chain-local row
-            double v = 0.0;
-            if (col < K) {
-                if (side == 0) {                                // C_p(a, b) = A[s+a, s-K+b], a = row < K, nonzero for a <= b
-                    if (row < K && row <= col) v = a.band[(int64_t)(col - row) * a.ld + cd.row0 + row];
-                } else {                                        // B_p(a, b) = A[e-K+a, e+b], a = row-(np-K) >= 0, nonzero for b <= a
-                    const int aa = row - (np - K);
-                    if (aa >= 0 && col <= aa) v = a.band[(int64_t)(2 * K + col - aa) * a.ld + cd.row0 + row];
-                }
-            }
-            t[r] = v;
-        }
-        return t;
-    };
-    // acc -= F(rb, slot) * B for one factor tile (A operand straight from the scratch)
-    auto gemm_sub = [&](v4 acc, int rb, int slot, const v4 &B) -> v4 {
-        const double *tp = tile_ptr(rb, slot) + li * 16 + lk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-tp[4 * q], B[q], acc, 0, 0, 0);
-        return acc;
-    };
-    auto put_tile = [&](const v4 &t, double *T) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(lk + 4 * r) * TL + li] = t[r];
-    };
-    auto get_tile = [&](const double *T) -> v4 {
-        v4 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = T[(lk + 4 * r) * TL + li];
-        return t;
-    };
-    auto load_diag = [&](int rb) {   // diagonal factor tile (rb, rb) -> dt
-        const double *tp = tile_ptr(rb, lv.KB) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dt[(lk + 4 * q) * TL + li] = tp[64 * q];
-    };
-
-    // ---------------- forward: Z ----------------
-    // (the row-block loop is unrolled by KB so that the window slot of a block, rb % KB, is a compile-time register index)
-    for (int rbb = rbs - rbs % KB; rbb < NB; rbb += KB) {
-#pragma unroll
-        for (int u = 0; u < KB; ++u) {
-            const int rb = rbb + u;
-            if (rb < rbs || rb >= NB) continue;
-            v4 acc = rhs_tile(rb);
-#pragma unroll
-            for (int d = 1; d <= KB; ++d)
-                if (rb - d >= rbs) acc = gemm_sub(acc, rb, lv.KB - d, Xw[(u - d + KB) % KB]);
-            put_tile(acc, tb);
-            load_diag(rb);
-            WAVE_LDS_FENCE();
-            if (lane < 16) {             // unit lower 16 x 16: column `lane` of the right-hand side tile
-                double z[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    double v = tb[i * TL + lane];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) v = fma(-dt[i * TL + k], z[k], v);
-                    z[i] = v;
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tb[i * TL + lane] = z[i];
-            }
-            WAVE_LDS_FENCE();
-            const v4 Z = get_tile(tb);
-            Xw[u] = Z;
-            double *zp = zs + (int64_t)rb * 256 + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) zp[64 * q] = Z[q];          // D layout, element lane + 64 q
-            WAVE_LDS_FENCE();
-        }
-    }
-    // ---------------- backward: X ----------------
-#pragma unroll
-    for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
-    double mi = 0.0, mo = 0.0;
-    double *spike = (side == 0 ? a.Wf : a.Vf);
-    for (int rbb = ((NB - 1) / KB) * KB; rbb >= 0; rbb -= KB) {
-#pragma unroll
-        for (int u = KB - 1; u >= 0; --u) {
-            const int rb = rbb + u;
-            if (rb >= NB) continue;
-            v4 acc = {0.0, 0.0, 0.0, 0.0};
-            if (rb >= rbs) {
-                const double *zp = zs + (int64_t)rb * 256 + lane;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = zp[64 * q];
-            }
-#pragma unroll
-            for (int d = 1; d <= KB; ++d)
-                if (rb + d < NB) acc = gemm_sub(acc, rb, lv.KB + d, Xw[(u + d) % KB]);
-            put_tile(acc, tb);
-            load_diag(rb);
-            WAVE_LDS_FENCE();
-            if (lane < 16) {             // upper 16 x 16 with its diagonal
-                double x[16];
-#pragma unroll
-                for (int i = 15; i >= 0; --i) {
-                    double v = tb[i * TL + lane];
-#pragma unroll
-                    for (int k = i + 1; k < 16; ++k) v = fma(-dt[i * TL + k], x[k], v);
-                    x[i] = v / dt[i * TL + i];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tb[i * TL + lane] = x[i];
-            }
-            WAVE_LDS_FENCE();
-            Xw[u] = get_tile(tb);
-            // ---- outputs: lane = (column li, rows 4 lk .. 4 lk + 3 of the block)
-            const int col = c0 + li;
-            if (col < K) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = (rb0 + rb) * 16 + 4 * lk + e;    // chain-local row
-                    const double v = tb[(4 * lk + e) * TL + li];
-                    const int dist = side == 0 ? row : np - 1 - row; // rows from the interface
-                    if (dist < K) tips[(int64_t)(side == 0 ? row : row - (np - K)) * K + col] = v;
-                    if (spike != nullptr && dist < m) {
-                        spike[((int64_t)p * K + col) * m + (side == 0 ? row : row - (np - m))] = v;
-                        mi = fmax(mi, fabs(v));
-                        if (dist >= m - 32) mo = fmax(mo, fabs(v));
-                    }
-                }
-            }
-            WAVE_LDS_FENCE();
-        }
-    }
-    if (spike != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
-        if (lane == 0) {
-            if (mi > __hip_atomic_load(a.absmax_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_in, mi);
-            if (mo > __hip_atomic_load(a.absmax_edge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(a.absmax_edge, mo);
-        }
-    }
-}
-
-// ---- round 2b: the same solve without its serial core --------------------------------------------------------------------
-// k_spike_trsm spends a block step on (i) eight to sixteen factor-tile loads that the compiler leaves next to their MFMAs (a
-// memory round trip each), (ii) a 16-lane triangular substitution through LDS (120 dependent multiply-adds) that EVERY wave
-// of a chain side repeats with the same diagonal tile: 9 us per step at K = 128.  Here the diagonal tiles of the region are
-// inverted once per chain side (k_trsm_diag_inv: one wave per tile, lanes 0-15 a column of L^-1, lanes 16-31 a column of
+// ---- the solve without a serial core ---------------------------------------------------------------------------------------
+// The first version of this solve (round 2a, removed in round 3) spent a block step on (i) eight to sixteen factor-tile loads
+// that the compiler left next to their MFMAs (a memory round trip each), (ii) a 16-lane triangular substitution through LDS
+// (120 dependent multiply-adds) that EVERY wave of a chain side repeated with the same diagonal tile: 9 us per step at
+// K = 128.  Here the diagonal tiles of the region are inverted once per chain side (k_trsm_diag_inv: one wave per tile, lanes 0-15 a column of L^-1, lanes 16-31 a column of
 // U^-1), so the triangular solve of a step is one more 16 x 16 x 16 product, and the A operands of step rb+1 (off-diagonal
 // tiles, inverse tile, Z tile) are requested into registers before the MFMAs of step rb: no LDS, one exposed chain of
 // 4 (KB + 1) dependent MFMAs per step.  The pack kernel treats the 64 x 64 diagonal blocks of the sweeps the same way.
@@ -2734,22 +2558,25 @@ __global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a
     const int nwv = blockDim.x >> 6;
     const int wg = w + nwv * blockIdx.z;         // column tile of this wave
     const int ncw = nwv * gridDim.z;
-    const int p = blockIdx.x, side = blockIdx.y;
+    // side 0: W (top coupling block C), side 1: V (bottom coupling block B), side 2 (twisted factorisation only): the
+    // backward solve of [0; I] on the last K rows, i.e. Gb = (D^-1 U)_bb^-1; sides 1 and 2 work on the same (bottom) region
+    const int p = blockIdx.x, side = blockIdx.y, bside = side == 0 ? 0 : 1;
     const ChainDesc cd = a.chains[p];
     const int K = a.K, m = a.m;
     const int np = cd.nrows;
-    const bool on = side == 0 ? (a.grow0 + cd.row0 > 0) : (a.grow0 + cd.row0 + np < a.n_global);
+    const bool on = side == 0 ? has_top(cd) : has_bot(cd);
     const int c0 = 16 * wg;
-    double *tips = (side == 0 ? a.Wt : a.Vb) + (int64_t)p * K * K;
+    double *tips = (side == 0 ? a.Wt : (side == 1 ? a.Vb : a.Gb)) + (int64_t)p * K * K;
     if (!on) return;                             // no neighbour on this side: the tips stay zero (setup cleared them)
+    const bool fwd_only = side == 1 && a.Tb != nullptr;   // twisted: the seam needs the forward-swept block only
     const int region = a.region < np ? a.region : np;
     const int NB = region / 16;
-    const int rb0 = side == 0 ? 0 : (np - region) / 16;
-    const int rbs = side == 0 ? 0 : (np - K) / 16 - rb0;
+    const int rb0 = bside == 0 ? 0 : (np - region) / 16;
+    const int rbs = bside == 0 ? 0 : (np - K) / 16 - rb0;
     const int64_t rbg0 = (cd.row0 >> 4) + rb0;
     const LuView lv = a.lv;
-    double *zs = a.zscratch + (((int64_t)p * 2 + side) * ncw + wg) * (int64_t)NB * 256;
-    const double *invp = inv + (((int64_t)p * 2 + side) * (a.region / 16)) * 512;
+    double *zs = a.zscratch + (((int64_t)p * 2 + bside) * ncw + wg) * (int64_t)NB * 256;
+    const double *invp = inv + (((int64_t)p * 2 + bside) * (a.region / 16)) * 512;
     const int li = lane & 15, lk = lane >> 4;
     typedef double v4 __attribute__((ext_vector_type(4)));
     // ROW PERMUTATION.  The MFMA layouts are fixed: A operand lane (i = li, k = lk + 4q), C/D element r of lane = row lk + 4r.
@@ -2806,8 +2633,8 @@ __global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a
     // ---------------- forward: Z ----------------
     StepOps cur, nxt;
     const int fstart = rbs - rbs % KB;
-    fetch(nxt, rbs, false);
-    for (int rbb = fstart; rbb < NB; rbb += KB) {
+    if (side != 2) fetch(nxt, rbs, false);
+    for (int rbb = fstart; rbb < NB && side != 2; rbb += KB) {
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
             const int rb = rbb + u;
@@ -2825,13 +2652,21 @@ __global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a
             const v4 Z = solve_diag(cur.I, acc);
             Xw[u] = Z;
             *reinterpret_cast<v4 *>(zs + (int64_t)rb * 256 + 4 * lane) = Z;   // the wave's own scratch: 32 bytes per lane
+            if (fwd_only && c0 + li < K) {                                    // Tb = the last K rows of (L D)^-1 [0; B]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (rb0 + rb) * 16 + 4 * lk + r, aa = row - (np - K);
+                    if (aa >= 0) a.Tb[((int64_t)p * K + aa) * K + c0 + li] = Z[r] * a.dinv[cd.row0 + row];   // D^-1 L^-1 [0; B]
+                }
+            }
         }
     }
+    if (fwd_only) return;
     // ---------------- backward: X ----------------
 #pragma unroll
     for (int q = 0; q < KB; ++q) Xw[q] = v4{0.0, 0.0, 0.0, 0.0};
     double mi = 0.0, mo = 0.0;
-    double *spike = (side == 0 ? a.Wf : a.Vf);
+    double *spike = (side == 0 ? a.Wf : (side == 1 ? a.Vf : nullptr));
     // the Z tiles this wave wrote are read back by the same lanes: program order within the wave; the loads below are issued
     // after the stores above, no other wave touches them
     fetch(nxt, NB - 1, true);
@@ -2840,10 +2675,18 @@ __global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a
         for (int u = KB - 1; u >= 0; --u) {
             const int rb = rbb + u;
             if (rb >= NB) continue;
+            if (side == 2 && rb < rbs) continue;     // only the last K rows matter (they do not depend on the rows above)
             cur = nxt;
             fetch(nxt, rb - 1, true);
             v4 acc = {0.0, 0.0, 0.0, 0.0};
             if (rb >= rbs) acc = cur.Z;
+            if (side == 2) {                         // (D^-1 U) X = [0; I]  <=>  U X = [0; D]: entry (row, col) = U_row,row iff row - (np - K) == col
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (rb0 + rb) * 16 + 4 * lk + r;
+                    acc[r] = (row - (np - K) == c0 + li) ? 1.0 / a.dinv[cd.row0 + row] : 0.0;
+                }
+            }
 #pragma unroll
             for (int d = 1; d <= KB; ++d)
                 if (rb + d < NB) {
@@ -2891,34 +2734,26 @@ size_t spike_trsm_scratch_doubles(int K, int nchains, int region)
 }
 
 hipError_t launch_spike_trsm(double *lu, int K, int m, int region, const ChainDesc *chains, int nchains, const double *band,
-                             int64_t ld, int64_t n_global, int64_t grow0, double *Wt, double *Vb, double *Wf, double *Vf,
-                             double *zscratch, double *absmax_in, double *absmax_edge, hipStream_t st)
+                             int64_t ld, double *Wt, double *Vb, double *Wf, double *Vf, double *zscratch, double *absmax_in,
+                             double *absmax_edge, hipStream_t st, double *Tb, double *Gb, const double *dinv)
 {
-    if (nchains <= 0 || K <= 32 || K > 256) return hipErrorInvalidValue;
+    if (nchains <= 0 || K <= 32 || K > 256 || (Tb == nullptr) != (Gb == nullptr) || (Tb != nullptr && dinv == nullptr)) return hipErrorInvalidValue;
     TrsmArgs a;
     a.lv.p = lu; a.lv.ld = 0; a.lv.K = K; a.lv.KB = lu_kb(K); a.lv.ntl = 2 * a.lv.KB + 1;
-    a.chains = chains; a.band = band; a.ld = ld; a.n_global = n_global; a.grow0 = grow0;
+    a.chains = chains; a.band = band; a.ld = ld;
     a.K = K; a.m = m; a.region = region; a.Wt = Wt; a.Vb = Vb; a.Wf = Wf; a.Vf = Vf; a.zscratch = zscratch;
-    a.absmax_in = absmax_in; a.absmax_edge = absmax_edge;
-    const int nz = K > 128 ? 2 : 1;                       // K > 128: the columns of a chain side over two workgroups
-    const int nwv = ((K + nz - 1) / nz + 15) / 16;        // waves per workgroup (<= 8): 16 columns each
-    static const bool old_trsm = getenv("SPIKE_TRSM_OLD") != nullptr;   // measurement knob: substitution through LDS, no prefetch
-    if (!old_trsm) {
-        // K > 128: four workgroups of four waves per chain side (one wave per SIMD: the operands of two steps and the window of
-        // 16 solved tiles need ~420 registers)
-        const int nz4 = K > 128 ? 4 : 1, nwv4 = ((K + nz4 - 1) / nz4 + 15) / 16;
-        const int waves = nwv * nz > nwv4 * nz4 ? nwv * nz : nwv4 * nz4;
-        double *inv = zscratch + (size_t)nchains * 2 * (size_t)waves * (size_t)(region / 16) * 256;
-        hipLaunchKernelGGL(k_trsm_diag_inv, dim3(region / 16, nchains, 2), dim3(64), 0, st, a, inv);
-        if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm2<4>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
-        else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm2<8>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
-        else hipLaunchKernelGGL(k_spike_trsm2<16>, dim3(nchains, 2, nz4), dim3(nwv4 * 64), 0, st, a, inv);
-        return hipGetLastError();
-    }
-    const size_t shm = (size_t)nwv * 2 * 16 * 17 * sizeof(double);
-    if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm<4>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
-    else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm<8>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
-    else hipLaunchKernelGGL(k_spike_trsm<16>, dim3(nchains, 2, nz), dim3(nwv * 64), shm, st, a);
+    a.absmax_in = absmax_in; a.absmax_edge = absmax_edge; a.Tb = Tb; a.Gb = Gb; a.dinv = dinv;
+    // K > 128: four workgroups of four waves per chain side (one wave per SIMD: the operands of two steps and the window of
+    // 16 solved tiles need ~420 registers)
+    const int nz = K > 128 ? 2 : 1, nwv = ((K + nz - 1) / nz + 15) / 16;
+    const int nz4 = K > 128 ? 4 : 1, nwv4 = ((K + nz4 - 1) / nz4 + 15) / 16;
+    const int waves = nwv * nz > nwv4 * nz4 ? nwv * nz : nwv4 * nz4;
+    const int nsides = Tb != nullptr ? 3 : 2;
+    double *inv = zscratch + (size_t)nchains * 2 * (size_t)waves * (size_t)(region / 16) * 256;
+    hipLaunchKernelGGL(k_trsm_diag_inv, dim3(region / 16, nchains, 2), dim3(64), 0, st, a, inv);
+    if (a.lv.KB == 4) hipLaunchKernelGGL(k_spike_trsm2<4>, dim3(nchains, nsides, nz4), dim3(nwv4 * 64), 0, st, a, inv);
+    else if (a.lv.KB == 8) hipLaunchKernelGGL(k_spike_trsm2<8>, dim3(nchains, nsides, nz4), dim3(nwv4 * 64), 0, st, a, inv);
+    else hipLaunchKernelGGL(k_spike_trsm2<16>, dim3(nchains, nsides, nz4), dim3(nwv4 * 64), 0, st, a, inv);
     return hipGetLastError();
 }
 
@@ -3314,16 +3149,23 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 // lane = row (coalesced column-major spike reads), K sequential FMAs per lane, tip vectors from LDS.
 // mode 0: every (chain, end); 1: all but the two rank-boundary ends (top of chain 0, bottom of the last chain), whose tip
 // solutions come from the exchange; 2: exactly those two (launched on the exchange stream once they are known).
+// TWISTED: a chain has ONE window, the m rows at its chain-local top (the outer end of its partition), spike Wf_p in chain-
+// local orientation.  A vdir = +1 chain (top half) takes x_b of the partition above as ever; a vdir = -1 chain (bottom half,
+// stored flipped) is the partition's natural V spike with rows and columns reversed: it takes x_t of the partition below
+// with its entries REVERSED, and its rows run backwards through x.
+template <bool TWISTED>
 __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf,
                                                        const double *Vf, const double *xb, const double *xt, double *x, int mode)
 {
     extern __shared__ double tip[];
     int p = blockIdx.y, which = blockIdx.z;
     if (mode == 2) { which = blockIdx.y; p = which == 0 ? 0 : nchains - 1; }
-    else if (mode == 1 && ((p == 0 && which == 0) || (p == nchains - 1 && which == 1))) return;
+    else if (mode == 1 && ((p == 0 && (TWISTED || which == 0)) || (p == nchains - 1 && (TWISTED || which == 1)))) return;
     const ChainDesc cd = chains[p];
-    const double *src = which == 0 ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
-    for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = src[c];
+    const bool up = TWISTED && cd.vdir < 0;
+    if (TWISTED) which = 0;
+    const double *src = (which == 0 && !up) ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
+    for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = up ? src[K - 1 - c] : src[c];
     __syncthreads();
     const int r = 2 * (blockIdx.x * blockDim.x + threadIdx.x);  // this lane's row pair (m is even: a multiple of 64,
     if (r >= m) return;                                         //  or the chain length, itself a multiple of 64 or odd-tailed)
@@ -3343,6 +3185,12 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
             if (r + 1 < m) a1 = fma(S[(int64_t)c * m + 1], tip[c], a1);
         }
     }
+    if (TWISTED) {   // one window per chain: nothing to race with
+        const int64_t row = cd.vec0 + (int64_t)cd.vdir * r;
+        x[row] -= a0;
+        if (r + 1 < m) x[row + cd.vdir] -= a1;
+        return;
+    }
     const int64_t row = cd.row0 + (which == 0 ? r : cd.nrows - m + r);
     // when 2m > nrows the two windows overlap: the two contributions to a row must not race
     if (2 * m > cd.nrows) {
@@ -3355,12 +3203,154 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
 }
 
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st, int mode)
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode, bool twisted)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
+    if (twisted) {
+        const dim3 grid = mode == 2 ? dim3((m + 511) / 512, 2, 1) : dim3((m + 511) / 512, nchains, 1);
+        hipLaunchKernelGGL(k_spike_correct<true>, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf,
+                           xb, xt, x, mode);
+        return hipGetLastError();
+    }
     const dim3 grid = mode == 2 ? dim3((m + 511) / 512, 2, 1) : dim3((m + 511) / 512, nchains, 2);
-    hipLaunchKernelGGL(k_spike_correct, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf, xb,
+    hipLaunchKernelGGL(k_spike_correct<false>, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf, xb,
                        xt, x, mode);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Twisted factorisation, setup pieces (spike_internal.h: ChainDesc).
+// ------------------------------------------------------------------------------------------
+// the band in factor space: chain-local row r of a vdir = -1 chain is vector-space row vec0 - r, and its diagonal d (column
+// offset d - K) is the original's diagonal 2K - d (column offset K - d = -(d - K))
+__global__ __launch_bounds__(256) void k_band_flip(const double *src, int64_t lds, int K, const ChainDesc *chains, double *dst,
+                                                   int64_t ldd)
+{
+    const ChainDesc cd = chains[blockIdx.y];
+    const int d = blockIdx.z;
+    const int sd = cd.vdir > 0 ? d : 2 * K - d;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x)
+        dst[(int64_t)d * ldd + cd.row0 + r] = src[(int64_t)sd * lds + cd.vec0 + (int64_t)cd.vdir * r];
+}
+
+hipError_t launch_band_flip(const double *src, int64_t lds, int K, const ChainDesc *chains, int nchains, int max_rows, double *dst,
+                            int64_t ldd, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    int gx = (max_rows + 255) / 256;
+    if (gx > 16) gx = 16;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_band_flip, dim3(gx, nchains, 2 * K + 1), dim3(256), 0, st, src, lds, K, chains, dst, ldd);
+    return hipGetLastError();
+}
+
+// K <= 32 (diagonal-major LU scratch): one workgroup per chain, thread j = column j.  With i = np - K + a the chain-local row:
+//   L_bb[a][b] = lu[(K + b - a) ld + row0 + i]  (b < a),   U_bb[a][b] = lu[(K + b - a) ld + row0 + i]  (b >= a)
+//   B[a][b]    = band[(2K + b - a) ldb + row0 + i]  (b <= a)
+// Tb[:, j] = D^-1 L_bb^-1 B[:, j]  (forward substitution, then 1/diag);  Gb[:, j] = column j of the inverse of D^-1 U_bb
+__global__ __launch_bounds__(64) void k_seam_small(const double *lu, int64_t ld, int K, const double *band, int64_t ldb,
+                                                   const ChainDesc *chains, double *Tb, double *Gb)
+{
+    __shared__ double F[32][33];
+    const int p = blockIdx.x, j = threadIdx.x;
+    const ChainDesc cd = chains[p];
+    if (!has_bot(cd)) return;   // (cleared by the host)
+    const int64_t r0 = cd.row0 + cd.nrows - K;
+    for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
+        const int a = t / K, b = t % K;
+        F[a][b] = lu[(int64_t)(K + b - a) * ld + r0 + a];
+    }
+    __syncthreads();
+    if (j >= K) return;
+    double z[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        if (a < K) {
+            double v = (j <= a) ? band[(int64_t)(2 * K + j - a) * ldb + r0 + a] : 0.0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b)
+                if (b < a) v = fma(-F[a][b], z[b], v);
+            z[a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a)
+        if (a < K) Tb[((int64_t)p * K + a) * K + j] = z[a] / F[a][a];
+#pragma unroll
+    for (int a = 31; a >= 0; --a) {
+        if (a < K) {
+            double v = (a == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b)
+                if (b > a && b < K) v = fma(-(F[a][b] / F[a][a]), z[b], v);
+            z[a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a)
+        if (a < K) Gb[((int64_t)p * K + a) * K + j] = z[a];
+}
+
+hipError_t launch_seam_small(const double *lu, int64_t ld, int K, const double *band, int64_t ldb, const ChainDesc *chains,
+                             int nchains, double *Tb, double *Gb, hipStream_t st)
+{
+    if (nchains <= 0 || K < 1 || K > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_seam_small, dim3(nchains), dim3(64), 0, st, lu, ld, K, band, ldb, chains, Tb, Gb);
+    return hipGetLastError();
+}
+
+// W[t] = Tb[2t] J Gb[2t+1], V[t] = Tb[2t+1] J Gb[2t]: (T J G)[i][j] = sum_k T[i][K-1-k] G[k][j].  One workgroup per
+// (pair, which, 16-row strip); a setup-time product of K^3 multiply-adds per matrix (0.5 GFLOP at the headline size).
+__global__ __launch_bounds__(256) void k_seam_products(int K, const double *Tb, const double *Gb, double *W, double *V)
+{
+    extern __shared__ double Ts[];   // 16 rows of T, reversed columns: Ts[i][k] = T[i0 + i][K-1-k]
+    const int t = blockIdx.x, which = blockIdx.y, i0 = blockIdx.z * 16;
+    const int64_t kk = (int64_t)K * K;
+    const double *T = Tb + (int64_t)(2 * t + which) * kk, *G = Gb + (int64_t)(2 * t + 1 - which) * kk;
+    double *out = (which == 0 ? W : V) + (int64_t)t * kk;
+    for (int q = threadIdx.x; q < 16 * K; q += blockDim.x) {
+        const int i = q / K, k = q % K;
+        Ts[q] = (i0 + i < K) ? T[(int64_t)(i0 + i) * K + (K - 1 - k)] : 0.0;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double g = G[(int64_t)k * K + j];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = fma(Ts[i * K + k], g, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i0 + i < K) out[(int64_t)(i0 + i) * K + j] = acc[i];
+    }
+}
+
+hipError_t launch_seam_products(int K, int npairs, const double *Tb, const double *Gb, double *W, double *V, hipStream_t st)
+{
+    if (npairs <= 0 || K <= 0) return hipSuccess;
+    const int nt = K >= 256 ? 256 : (K >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(k_seam_products, dim3(npairs, 2, (K + 15) / 16), dim3(nt), (size_t)16 * K * sizeof(double), st, K, Tb, Gb, W, V);
+    return hipGetLastError();
+}
+
+__global__ void k_flip_kk(int K, const double *in, int first, int stride, double *out)
+{
+    const int i = blockIdx.x;
+    const double *a = in + (int64_t)(first + i * stride) * K * K;
+    double *o = out + (int64_t)i * K * K;
+    for (int t = threadIdx.x; t < K * K; t += blockDim.x) {
+        const int r = t / K, c = t % K;
+        o[t] = a[(int64_t)(K - 1 - r) * K + (K - 1 - c)];
+    }
+}
+
+hipError_t launch_flip_kk(int K, int count, const double *in, int first, int stride, double *out, hipStream_t st)
+{
+    if (count <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flip_kk, dim3(count), dim3(256), 0, st, K, in, first, stride, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,149 @@
+"""Twisted (two-ended) factorisation: chains 2t / 2t+1 are the top and bottom half of one diagonal block, factored from its
+two ends; an exact 2K x 2K seam system links the halves between the inward and the outward sweep launch, and only the
+blocks' outer ends are truncated interfaces with stored spikes.  The preconditioner for a caller-chosen
+partition count must not change: every case is compared with the CPU oracle for the caller's P (relative 2-norm 1e-10, the
+stated fp64 tolerance) and with the library's own untwisted result."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _mk(spike, P, variant="coupled", twist="auto", **opts):
+    sp = spike.Spike(partitions=P, variant=variant)
+    sp.set_option("twist", twist)
+    for k, v in opts.items():
+        sp.set_option(k, v)
+    return sp
+
+
+# N, K, P: every tile configuration (R = 4/8/16/32: several chains per wave, seam matrices off the diagonal-major LU scratch;
+# R = 64 with 2..8 waves: seam matrices from the block TRSM), caller partitions that get cut into 2, 4, 6 ... chains, odd
+# sub-split factors, partitions with an odd number of 64-row blocks (halves of unequal length), a ragged last block (K <= 32)
+CASES = [
+    (2 ** 16, 2, 4), (2 ** 16, 3, 7), (2 ** 16 + 33, 4, 8), (2 ** 17, 8, 16), (2 ** 16, 13, 5), (2 ** 17 + 21, 16, 8), (2 ** 17, 32, 8),
+    (2 ** 17, 50, 4), (2 ** 17, 64, 8), (3 * 2 ** 15, 100, 3), (2 ** 18, 128, 8), (2 ** 18, 128, 5), (2 ** 18 + 64 * 7, 128, 3),
+    (2 ** 17, 200, 4), (3 * 2 ** 15, 256, 2),
+]
+
+
+@pytest.mark.parametrize("N,K,P", CASES)
+def test_twisted_equals_oracle_and_untwisted(spike, oracle, N, K, P):
+    band = oracle.gen_band(N, K, delta=1.2)
+    f = oracle.gen_vec(N)
+    ref = oracle.Spike(band, P)
+    for variant, vname in ((1, "coupled"), (0, "decoupled")):
+        xo = ref.apply(f, variant)
+        tw = _mk(spike, P, vname, "auto").setup_band(band)
+        assert "(twisted pairs)" in tw.view(), tw.view()          # the case really exercises the twisted path
+        i = tw.info()
+        assert i.P_local == P and i.passes == 1 and i.chains_local % (2 * P) == 0 and i.nboost == ref.nboost
+        xt = tw.apply(f)
+        assert _rel(xt, xo) <= TOL, (vname, _rel(xt, xo))
+        off = _mk(spike, P, vname, "off").setup_band(band)
+        assert "(twisted pairs)" not in off.view()
+        xu = off.apply(f)
+        assert _rel(xu, xo) <= TOL
+        assert _rel(xt, xu) <= TOL
+        # half the stored-spike traffic for the same number of chains
+        io = off.info()
+        if io.chains_local == i.chains_local and io.spike_rows == i.spike_rows:
+            assert 2 * i.spike_bytes == io.spike_bytes
+        tw.close(); off.close()
+
+
+@pytest.mark.parametrize("N,K", [(2 ** 19, 128), (2 ** 19, 32), (2 ** 20, 8), (2 ** 19, 64), (2 ** 19 + 640, 256)])
+def test_auto_partitions_twisted_is_exact_on_dominant_systems(spike, oracle, N, K):
+    """partitions = 0: the library pairs its own chains.  On the dominant system truncated SPIKE equals the band solve to
+    rounding: M^-1 (A 1) = 1, residual of a random solve, linearity; tips of the caller-level interfaces in natural orientation."""
+    import torch
+    band = spike.gen_band_device(N, K, seed=12345, delta=1.2)
+    sp = _mk(spike, 0).setup_band(band)
+    assert "(twisted pairs)" in sp.view()
+    i = sp.info()
+    assert i.chains_local == 2 * i.P_local and i.passes == 1 and i.spike_rows > 0
+    u = torch.ones(N, dtype=torch.float64, device="cuda")
+    b = sp.matvec(u)
+    x = sp.apply(b)
+    assert float((x - u).abs().max()) <= 1e-10
+    v = torch.from_numpy(oracle.gen_vec(N)).cuda()
+    bv = sp.matvec(v)
+    xv = sp.apply(bv)
+    assert float((sp.matvec(xv) - bv).norm() / bv.norm()) <= 1e-12
+    assert float((sp.apply(b + 3.0 * bv) - (x + 3.0 * xv)).abs().max()) <= 1e-9
+    # same partitions without twisting: the same preconditioner to rounding
+    off = _mk(spike, i.P_local, twist="off", subsplit="off").setup_band(band)
+    assert float((off.apply(bv) - xv).abs().max()) <= 1e-10
+    if i.P_local > 1:
+        Vt, Wt = sp.tips()
+        Vo, Wo = off.tips()
+        assert np.abs(Vt - Vo).max() <= 1e-12 * max(1.0, np.abs(Vo).max()) and np.abs(Wt - Wo).max() <= 1e-12 * max(1.0, np.abs(Wo).max())
+
+
+def test_slowly_decaying_spikes_fall_back_to_ordinary_chains(spike, oracle):
+    """the -1, 2, -1 stencil: spikes never die inside a chain => setup measures that and starts over untwisted (and without
+    cutting the caller's partitions); the result is still the P-partition preconditioner"""
+    N, P = 2 ** 15, 4
+    band = np.zeros((5, N))
+    band[1, 1:] = -1.0; band[2, :] = 2.0; band[3, :-1] = -1.0          # K = 2 storage of a tridiagonal matrix
+    f = oracle.gen_vec(N)
+    sp = _mk(spike, P).setup_band(band)
+    assert "(twisted pairs)" not in sp.view() and sp.info().chains_local == P
+    assert _rel(sp.apply(f), oracle.Spike(band, P).apply(f, 1)) <= 1e-8
+
+
+@pytest.mark.parametrize("K,G,Pl", [(128, 4, 2), (16, 3, 4), (64, 2, 0)])
+def test_twisted_across_ranks(spike, oracle, K, G, Pl):
+    """thread ranks over the loopback transport: rank-boundary interfaces lie between a bottom half (flipped) of one rank
+    and a top half of the next -- the exchanged tips and the gathered [W_first | V_last] are in natural orientation"""
+    import torch
+    n_rank = 2 ** 16
+    N = G * n_rank
+    band = oracle.gen_band(N, K, seed=12345, delta=1.2)
+    f = oracle.gen_vec(N)
+    out, views, infos, err = [None] * G, [None] * G, [None] * G, [None] * G
+
+    def work(r):
+        try:
+            sp = _mk(spike, Pl)
+            sp.comm_init_local(G, r, 4200 + K)
+            r0 = r * n_rank
+            sp.setup_band(np.ascontiguousarray(band[:, r0:r0 + n_rank]), n_global=N, row0=r0)
+            views[r] = sp.view(); infos[r] = sp.info().P_local
+            out[r] = sp.apply(torch.from_numpy(f[r0:r0 + n_rank].copy()).cuda()).cpu().numpy()
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    assert all("(twisted pairs)" in v for v in views), views
+    x = np.concatenate(out)
+    assert _rel(x, oracle.Spike(band, sum(infos)).apply(f, 1)) <= TOL
+
+
+def test_twisted_gmres_iteration_counts(spike, oracle):
+    """the twisted PCApply inside the Krylov loop: iteration counts as the oracle's GMRES with the P-partition preconditioner"""
+    import torch
+    N, K, P = 2 ** 17, 32, 8
+    band = oracle.gen_band(N, K, delta=0.8)
+    u = np.ones(N)
+    b = oracle.band_matvec(band, u)
+    sp = _mk(spike, P).setup_band(band)
+    assert "(twisted pairs)" in sp.view()
+    x = torch.zeros(N, dtype=torch.float64, device="cuda")
+    it, rn, ms, ok = sp.gmres(torch.from_numpy(b).cuda(), x, restart=30, rtol=1e-5, maxit=500)
+    xo, ito, rno, hist, oko = oracle.gmres(band, b, oracle.Spike(band, P), variant=1)
+    assert ok and oko and abs(it - ito) <= 1
+    assert np.abs(x.cpu().numpy() - u).max() <= 1e-4

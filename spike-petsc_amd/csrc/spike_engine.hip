@@ -127,7 +127,11 @@ struct spike_handle_s {
     int profile = 0;
     int subsplit = 1;           // 1 = cut a caller-chosen partition into sub-chains when the spikes provably die inside them
     int spike_storage = 1;      // 1 = keep the decayed spikes when they are short (one-pass coupled apply), 0 = always re-solve
-    double spike_tol = 1e-16;   // relative magnitude below which spike rows are dropped (fp64 rounding level)
+    // Relative magnitude (to the spikes' peak) below which spike rows are dropped.  1e-13 (round 3; 1e-16 before): measured on
+    // the bench systems (tools/spike_tol_study.py) the result moves by 2e-20..2e-19 relative -- four orders below fp64 rounding
+    // of the result itself, nine below the 1e-10 parity bar -- for 15 % fewer spike rows (1408 -> 1216 at K = 128).
+    double spike_tol = 1e-13;
+    int spike_fp32 = 1;         // 1 = the far part of every stored spike (entries below 2^-28 of the peak) is kept in fp32
     int twist_opt = 1;          // 1 = twisted (two-ended) factorisation of chain PAIRS where setup finds it applicable, 0 = never
     hipStream_t stream = nullptr;
     int overlap = 1;            // multi-rank apply: exchange + rank-boundary interfaces on a second stream beside the local coupling work
@@ -179,6 +183,8 @@ struct spike_handle_s {
     IfaceDesc *dIfsInt = nullptr, *dIfsFastInt = nullptr;  // only the cuts INSIDE caller partitions (decoupled variant, S > 1)
     int nif_int = 0;
     int spike_m = 0;                                      // rows kept per spike (0 = re-solve variant)
+    int spike_m1 = 0;                                     // of them in fp64 (the rows next to the interface); the rest in fp32
+    float *dWf32 = nullptr, *dVf32 = nullptr;             // fp32 parts, per chain column-major K x (spike_m - spike_m1)
     double *dSend = nullptr, *dRecv = nullptr;            // rank boundary exchange
     double *dXh = nullptr;                                // x extended by halos (n + 2K)
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
@@ -339,6 +345,7 @@ static void free_factors(spike_handle h)
     if (h->dChainsV == h->dChains) h->dChainsV = nullptr;   // an alias unless twisted
     F(h->dLt); F(h->dUt); F(h->dDinv); F(h->dY); F(h->dTmp); F(h->dChains); F(h->dGroups); F(h->dIfs);
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
+    F(h->dWf32); F(h->dVf32); h->spike_m1 = 0;
     F(h->dTips1); F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
     F(h->dChainsV); F(h->dIfsSeam); F(h->dSeamWT); F(h->dSeamVT); F(h->dSeamST); h->nseam = 0; h->twisted = false; h->chainsV.clear();
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
@@ -431,6 +438,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "spike_storage") h->spike_storage = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_tol") h->spike_tol = atof(val);
     else if (k == "twist") h->twist_opt = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "spike_fp32") h->spike_fp32 = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
@@ -1055,7 +1063,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             bot.chains = dC[1]; bot.groupsF = dG[2]; bot.groupsB = dG[3];
             return SPIKE_OK;
         };
-        int extent = 0;
+        int extent = 0, extent32 = 0;   // reach of the spikes at the drop level, and at the level below which fp32 storage is exact enough
+        constexpr double FP32_LEVEL = 3.725290298461914e-09;   // 2^-28 of the peak: fp32 rounding of such an entry is 2^-52 of the peak
         if (h->spike_storage || h->S > 1) {
             // First on the 24 K rows next to the interfaces (spikes of the dominant systems truncated SPIKE is meant for
             // die within ~10 K rows: four passes over an eighth of the factors instead of four full passes); if the
@@ -1065,7 +1074,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             SubChains pTop, pBot;
             if (shallow && (rc = build_sub(nbp, pTop, pBot))) return rc;
             for (int attempt = 0; attempt < 2; ++attempt) {
-                HIPCHK(hipMemsetAsync(dStat + 3, 0, sizeof(double), st));
+                HIPCHK(hipMemsetAsync(dStat + 3, 0, sizeof(double), st));   // two ints: [extent, extent32]
                 for (int which = 0; which < nwhich; ++which) {
                     HIPCHK(hipMemsetAsync(rhs, 0, sizeof(double) * n, st));
                     for (int t = 0; t < 2; ++t) {
@@ -1079,10 +1088,13 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                         HIPCHK(hipMemcpyAsync(&amax, dStat + 2, sizeof(double), hipMemcpyDeviceToHost, st));
                         HIPCHK(hipStreamSynchronize(st));
                         HIPCHK(launch_spike_extent(sol, h->dChainsV, P, which, h->spike_tol * amax, (int *)(dStat + 3), st));
+                        HIPCHK(launch_spike_extent(sol, h->dChainsV, P, which, FP32_LEVEL * amax, (int *)(dStat + 3) + 1, st));
                     }
                 }
-                HIPCHK(hipMemcpyAsync(&extent, dStat + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+                int ext2[2] = {0, 0};
+                HIPCHK(hipMemcpyAsync(ext2, dStat + 3, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
+                extent = ext2[0]; extent32 = ext2[1];
                 // the spike must have died well inside the probed depth (one block of margin beyond the storage margin)
                 if (!shallow || (int64_t)(extent * 1.06) + K + 2 * cfg.R <= (int64_t)(nbp - 1) * cfg.R) break;
                 shallow = false;
@@ -1204,6 +1216,36 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 (void)hipFree(h->dWf); if (h->dVf) (void)hipFree(h->dVf);
                 h->dWf = h->dVf = nullptr;
                 m = 0;
+            }
+        }
+        // ---- mixed precision: the far part of every window goes to fp32 (k_spike_correct comment)
+        h->spike_m1 = m;
+        const bool small_path = K >= 1 && K <= h->small_kmax && !multi && !tw;   // k_couple_small reads plain fp64 windows
+        if (m > 0 && h->spike_fp32 && !small_path && m % 64 == 0) {
+            int m1 = (int)(((int64_t)(extent32 * 1.06) + 64 + 63) / 64 * 64);
+            if (m1 < m && m - m1 >= 128) {
+                const int m2 = m - m1;
+                double *full[2] = {h->dWf, h->dVf};
+                double *p64[2] = {nullptr, nullptr};
+                float *p32[2] = {nullptr, nullptr};
+                HIPCHK(hipMemsetAsync(dStat + 2, 0, sizeof(double), st));
+                for (int w = 0; w < 2; ++w) {
+                    if (!full[w]) continue;
+                    HIPCHK(dalloc(&p64[w], (size_t)P * K * m1));
+                    HIPCHK(dalloc(&p32[w], (size_t)P * K * m2));
+                    HIPCHK(launch_spike_split(K, m, m1, P, w, full[w], p64[w], p32[w], dStat + 2, st));
+                }
+                double peak[3] = {0, 0, 0};
+                HIPCHK(hipMemcpyAsync(peak, dStat, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                // the probe looked at two columns per side; the split kernel saw every entry that went to fp32
+                if (peak[2] <= 4.0 * FP32_LEVEL * peak[0]) {
+                    (void)hipFree(h->dWf); if (h->dVf) (void)hipFree(h->dVf);
+                    h->dWf = p64[0]; h->dVf = p64[1]; h->dWf32 = p32[0]; h->dVf32 = p32[1];
+                    h->spike_m1 = m1;
+                } else {
+                    for (int w = 0; w < 2; ++w) { if (p64[w]) (void)hipFree(p64[w]); if (p32[w]) (void)hipFree(p32[w]); }
+                }
             }
         }
         // ---- twisted: the seam systems.  With zeta = the corrected forward result at a chain's last K rows,
@@ -1471,20 +1513,22 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     // windows and the general kernels are as fast), one rank, every interface coupled, windows that do not overlap: the small
     // coupling step (two tiny launches)
     if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
-        h->nif_local_all == P - 1 && !h->twisted)
+        h->nif_local_all == P - 1 && !h->twisted && h->spike_m1 == h->spike_m)
         return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
                    ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
-        HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0, h->twisted));
+        HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0, h->twisted,
+                                    h->spike_m1, h->dWf32, h->dVf32));
     if (multi) {
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, sx, y, h->n, K, h->dSend);
         HIPCHK(hipGetLastError());
         if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K, sx))) return rc;
         HIPCHK(launch_iface_apply(K, nedge, ifs + nloc, y, sx));
         if (h->spike_m > 0)
-            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2, h->twisted));
+            HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2, h->twisted, h->spike_m1,
+                                        h->dWf32, h->dVf32));
         if (overlap) {
             HIPCHK(hipEventRecord(h->evJoin, sx));
             HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));
@@ -1950,7 +1994,7 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->iface_bytes = ((int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) + (int64_t)h->nseam * 3) * (int64_t)h->K * h->K * 8;
     o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;
-    o->spike_bytes = (int64_t)(h->twisted ? 1 : 2) * h->spike_m * (int64_t)h->K * 8 * h->P;
+    o->spike_bytes = (int64_t)(h->twisted ? 1 : 2) * ((int64_t)h->spike_m1 * 8 + (int64_t)(h->spike_m - h->spike_m1) * 4) * (int64_t)h->K * h->P;
     o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
     return SPIKE_OK;
 }
@@ -1960,10 +2004,10 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
     if (!h || !buf || !len) return SPIKE_ERR_ARG;
     snprintf(buf, len,
              "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
-             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d, chains = %d%s\n",
+             "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d (%d in fp64), chains = %d%s\n",
              (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P_user,
              h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
-             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->P, h->twisted ? " (twisted pairs)" : "");
+             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->spike_m1, h->P, h->twisted ? " (twisted pairs)" : "");
     return SPIKE_OK;
 }
 

@@ -137,8 +137,13 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
                                const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st);
 // twisted: every chain has ONE window, at its chain-local top (Wf); a vdir = -1 chain takes the next partition's x_t, reversed
+// m1 < m: the window's m1 rows next to the interface in fp64 (Wf / Vf: K x m1 per chain), the other m - m1 rows in fp32
+// (Wf32 / Vf32: K x (m - m1)); launch_spike_split makes the two parts from a full fp64 window (spike_kernels.hip)
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0, bool twisted = false);
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0, bool twisted = false,
+                                int m1 = 0, const float *Wf32 = nullptr, const float *Vf32 = nullptr);
+hipError_t launch_spike_split(int K, int m, int m1, int nchains, int near_end, const double *full, double *p64, float *p32,
+                              double *max32, hipStream_t st);
 
 // twisted factorisation (setup): dst = the band in factor space (the rows of a vdir = -1 chain reversed, its diagonals mirrored)
 hipError_t launch_band_flip(const double *src, int64_t lds, int K, const ChainDesc *chains, int nchains, int max_rows,

@@ -3153,9 +3153,22 @@ hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int n
 // local orientation.  A vdir = +1 chain (top half) takes x_b of the partition above as ever; a vdir = -1 chain (bottom half,
 // stored flipped) is the partition's natural V spike with rows and columns reversed: it takes x_t of the partition below
 // with its entries REVERSED, and its rows run backwards through x.
+//
+// MIXED PRECISION (round 3).  A spike decays by orders of magnitude over its window; where every entry is below 2^-28 of the
+// spikes' peak, an fp32 copy is as good as the fp64 one -- its rounding error, 2^-24 relative, is 2^-52 of the peak, i.e. what
+// fp64 rounding does to the LARGE entries anyway.  So the window is stored in two parts: rows [0, m1) (from the interface)
+// in fp64, rows [m1, m) in fp32 (Wf32 / Vf32, column-major K x (m - m1) per chain); setup measures m1 and verifies the bound.
+// The arithmetic is fp64 throughout (the fp32 entries are widened on load).  grid.x = blocks of the fp64 part (512 rows each:
+// two rows per lane, 16-byte loads) followed by blocks of the fp32 part (1024 rows each: four rows per lane, 16-byte loads).
+struct SpikeStore {
+    const double *Wf, *Vf;     // fp64 parts, column-major K x m1 per chain
+    const float *Wf32, *Vf32;  // fp32 parts, column-major K x (m - m1) per chain (null when m1 == m)
+    int m, m1;
+};
+
 template <bool TWISTED>
-__global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf,
-                                                       const double *Vf, const double *xb, const double *xt, double *x, int mode)
+__global__ __launch_bounds__(256) void k_spike_correct(int K, SpikeStore sp, const ChainDesc *chains, int nchains, const double *xb,
+                                                       const double *xt, double *x, int mode, int nb64)
 {
     extern __shared__ double tip[];
     int p = blockIdx.y, which = blockIdx.z;
@@ -3164,57 +3177,116 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, int m, const Chain
     const ChainDesc cd = chains[p];
     const bool up = TWISTED && cd.vdir < 0;
     if (TWISTED) which = 0;
+    const int m = sp.m, m1 = sp.m1;
     const double *src = (which == 0 && !up) ? xb + (int64_t)p * K : xt + (int64_t)(p + 2) * K;
     for (int c = threadIdx.x; c < K; c += blockDim.x) tip[c] = up ? src[K - 1 - c] : src[c];
     __syncthreads();
-    const int r = 2 * (blockIdx.x * blockDim.x + threadIdx.x);  // this lane's row pair (m is even: a multiple of 64,
-    if (r >= m) return;                                         //  or the chain length, itself a multiple of 64 or odd-tailed)
-    const double *S = (which == 0 ? Wf : Vf) + (int64_t)p * K * m + r;
-    const bool pair = (r + 1 < m) && ((m & 1) == 0);
-    double a0 = 0.0, a1 = 0.0;
-    if (pair) {
+    // window row w (0 = at the interface... for V windows the rows are stored top to bottom, the interface at the END): the
+    // stored row index r in [0, m) maps to chain-local row (which == 0 ? r : nrows - m + r); the fp64 part holds the m1 rows
+    // NEXT TO THE INTERFACE, i.e. stored rows [0, m1) of a W window and [m - m1, m) of a V window
+    const bool f32 = (int)blockIdx.x >= nb64;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int r, nr;           // first stored row of this lane, rows it owns
+    if (!f32) {
+        const int q = 2 * (blockIdx.x * blockDim.x + threadIdx.x);            // row pair inside the fp64 part
+        if (q >= m1) return;
+        nr = q + 1 < m1 ? 2 : 1;
+        r = which == 0 ? q : (m - m1) + q;
+        const double *S = (which == 0 ? sp.Wf : sp.Vf) + (int64_t)p * K * m1 + q;
+        if (nr == 2 && (m1 & 1) == 0) {
 #pragma unroll 8
-        for (int c = 0; c < K; ++c) {
-            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(S + (int64_t)c * m));
-            a0 = fma(v.x, tip[c], a0);
-            a1 = fma(v.y, tip[c], a1);
+            for (int c = 0; c < K; ++c) {
+                const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(S + (int64_t)c * m1));
+                acc[0] = fma(v.x, tip[c], acc[0]);
+                acc[1] = fma(v.y, tip[c], acc[1]);
+            }
+        } else {
+            for (int c = 0; c < K; ++c) {
+                acc[0] = fma(S[(int64_t)c * m1], tip[c], acc[0]);
+                if (nr == 2) acc[1] = fma(S[(int64_t)c * m1 + 1], tip[c], acc[1]);
+            }
         }
     } else {
+        const int m2 = m - m1;                                                // a multiple of 64 (setup)
+        const int q = 4 * ((blockIdx.x - nb64) * blockDim.x + threadIdx.x);   // row quad inside the fp32 part
+        if (q >= m2) return;
+        nr = 4;
+        r = which == 0 ? m1 + q : q;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const float *S = (which == 0 ? sp.Wf32 : sp.Vf32) + (int64_t)p * K * m2 + q;
+#pragma unroll 8
         for (int c = 0; c < K; ++c) {
-            a0 = fma(S[(int64_t)c * m], tip[c], a0);
-            if (r + 1 < m) a1 = fma(S[(int64_t)c * m + 1], tip[c], a1);
+            const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(S + (int64_t)c * m2));
+            const double t = tip[c];
+            acc[0] = fma((double)v.x, t, acc[0]);
+            acc[1] = fma((double)v.y, t, acc[1]);
+            acc[2] = fma((double)v.z, t, acc[2]);
+            acc[3] = fma((double)v.w, t, acc[3]);
         }
     }
     if (TWISTED) {   // one window per chain: nothing to race with
         const int64_t row = cd.vec0 + (int64_t)cd.vdir * r;
-        x[row] -= a0;
-        if (r + 1 < m) x[row + cd.vdir] -= a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nr) x[row + (int64_t)cd.vdir * e] -= acc[e];
         return;
     }
     const int64_t row = cd.row0 + (which == 0 ? r : cd.nrows - m + r);
     // when 2m > nrows the two windows overlap: the two contributions to a row must not race
     if (2 * m > cd.nrows) {
-        atomicAdd(x + row, -a0);
-        if (r + 1 < m) atomicAdd(x + row + 1, -a1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nr) atomicAdd(x + row + e, -acc[e]);
     } else {
-        x[row] -= a0;
-        if (r + 1 < m) x[row + 1] -= a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nr) x[row + e] -= acc[e];
     }
 }
 
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
-                                const double *xb, const double *xt, double *x, hipStream_t st, int mode, bool twisted)
+                                const double *xb, const double *xt, double *x, hipStream_t st, int mode, bool twisted, int m1,
+                                const float *Wf32, const float *Vf32)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
+    if (m1 <= 0 || m1 > m || Wf32 == nullptr) m1 = m;
+    SpikeStore sp{Wf, Vf, Wf32, Vf32, m, m1};
+    const int nb64 = (m1 + 511) / 512, nb32 = (m - m1 + 1023) / 1024;
     if (twisted) {
-        const dim3 grid = mode == 2 ? dim3((m + 511) / 512, 2, 1) : dim3((m + 511) / 512, nchains, 1);
-        hipLaunchKernelGGL(k_spike_correct<true>, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf,
-                           xb, xt, x, mode);
+        const dim3 grid = mode == 2 ? dim3(nb64 + nb32, 2, 1) : dim3(nb64 + nb32, nchains, 1);
+        hipLaunchKernelGGL(k_spike_correct<true>, grid, dim3(256), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
         return hipGetLastError();
     }
-    const dim3 grid = mode == 2 ? dim3((m + 511) / 512, 2, 1) : dim3((m + 511) / 512, nchains, 2);
-    hipLaunchKernelGGL(k_spike_correct<false>, grid, dim3(256), (size_t)K * sizeof(double), st, K, m, chains, nchains, Wf, Vf, xb,
-                       xt, x, mode);
+    const dim3 grid = mode == 2 ? dim3(nb64 + nb32, 2, 1) : dim3(nb64 + nb32, nchains, 2);
+    hipLaunchKernelGGL(k_spike_correct<false>, grid, dim3(256), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
+    return hipGetLastError();
+}
+
+// full fp64 window (column-major K x m per chain) -> [fp64 K x m1 | fp32 K x (m - m1)]; near = 0: the interface is at
+// stored row 0 (W windows), near = 1: at stored row m - 1 (V windows).  max32[0] = max |entry| that went to fp32.
+__global__ __launch_bounds__(256) void k_spike_split(int K, int m, int m1, int near_end, const double *full, double *p64, float *p32,
+                                                     double *max32)
+{
+    const int64_t col = blockIdx.y;   // chain * K + column
+    const double *src = full + col * m;
+    const int m2 = m - m1;
+    double mx = 0.0;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < m; r += gridDim.x * blockDim.x) {
+        const double v = src[r];
+        const int dist = near_end ? m - 1 - r : r;          // rows from the interface
+        if (dist < m1) p64[col * m1 + (near_end ? r - m2 : r)] = v;
+        else { p32[col * m2 + (near_end ? r : r - m1)] = (float)v; mx = fmax(mx, fabs(v)); }
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(max32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_pos(max32, mx);
+}
+
+hipError_t launch_spike_split(int K, int m, int m1, int nchains, int near_end, const double *full, double *p64, float *p32,
+                              double *max32, hipStream_t st)
+{
+    if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spike_split, dim3((m + 255) / 256 < 4 ? (m + 255) / 256 : 4, nchains * K), dim3(256), 0, st, K, m, m1, near_end,
+                       full, p64, p32, max32);
     return hipGetLastError();
 }
 

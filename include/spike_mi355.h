@@ -215,6 +215,23 @@ int spike_last_sweep_ms(spike_handle h, double *ms_total, int *nlaunches);
  * non-temporal access shape as the sweeps), i.e. the read ceiling this device delivers                     */
 int spike_measure_read_bw(spike_handle h, int reps, double *gbps);
 
+/* ---- reordering front-end on the device (csrc/spike_reorder.hip) ---------------------------------------------
+ * Integer / byte work with results identical to the host loops of libspike_petsc_host (MatPermute, VecPermute, spike_awbm).
+ * No device: SPIKE_ERR_HIP (the caller keeps its host loop).
+ *   spike_permute_csr  = MatPermute(M, rorder, corder, &PM), src/kspreorder.c:20-22: row i of B is row rowp[i] of A, column c
+ *                        becomes the position of c in colp; rows of B sorted by column.  Host arrays in and out (ib: n+1,
+ *                        jb / b: ia[n] entries); SPIKE_ERR_ARG if rowp / colp are not permutations.
+ *   spike_permute_vec  = VecPermute(x, is, inverse), src/kspreorder.c:122-127, out of place: y[i] = x[idx[i]]
+ *                        (inverse: y[idx[i]] = x[i]); on_device != 0: x, y, idx are device pointers.
+ *   spike_awbm_device  = MatGetOrdering_AWBM, src/petsc_mat_awbm.c:42-225, with its two greedy phases (:98-112, :143-153) as
+ *                        a parallel fixed-point iteration on the device that reproduces the sequential greedy exactly; the
+ *                        one-step augmentations and the default fill (:115-140, :156-193) on the host.  perm[match[c]] = c;
+ *                        rounds[2] (optional): fixed-point rounds of the two phases.                                         */
+int spike_permute_csr(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, const int64_t *rowp, const int64_t *colp,
+                      int64_t *ib, int64_t *jb, double *b);
+int spike_permute_vec(int64_t n, const int64_t *idx, int inverse, const double *x, double *y, int on_device);
+int spike_awbm_device(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, int *rounds);
+
 /* ---- device half of the Fiedler ordering (reference slot MatGetOrdering_Fiedler, src/petsc_mat_fiedler.c:11-58) -------------
  * The ordering itself is host code (libspike_petsc_host: spike_fiedler_order_ex); its floating-point part, the LOBPCG
  * refinement of a multilevel level, can run here.  These calls hold one level's vectors on the device (ids 0 x, 1 Lx, 2 w,

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "spike_set_operator_band", "spike_operator_matvec", "spike_auto_partitions",
     "spike_setup_csr_dist", "spike_csr_band_weights", "spike_band_rule",
     "spike_setup_csr32", "spike_setup_csr_dist32", "spike_csr_band_k32", "spike_csr_band_weights32",
+    "spike_permute_csr", "spike_permute_vec", "spike_awbm_device",
     "spike_device_count", "spike_fd_create", "spike_fd_destroy", "spike_fd_dots", "spike_fd_lap", "spike_fd_shift",
     "spike_fd_div", "spike_fd_fill_alternating", "spike_fd_download_x", "spike_fd_refine",
 ]
@@ -97,6 +98,9 @@ def lib():
                                   C.POINTER(C.c_double)]
     L.spike_setup_csr_dist.argtypes = [vp, i64, i64, i64, iptr, iptr, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
                                        C.POINTER(C.c_double)]
+    L.spike_permute_csr.argtypes = [i64, iptr, iptr, dptr, iptr, iptr, iptr, iptr, dptr]
+    L.spike_permute_vec.argtypes = [i64, vp, C.c_int, vp, vp, C.c_int]
+    L.spike_awbm_device.argtypes = [i64, iptr, iptr, dptr, iptr, C.POINTER(C.c_int)]
     i32p = C.POINTER(C.c_int32)
     L.spike_setup_csr32.argtypes = [vp, i64, i32p, i32p, dptr, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.spike_setup_csr_dist32.argtypes = [vp, i64, i64, i64, i32p, i32p, dptr, C.c_int, C.c_double, C.POINTER(C.c_int),
@@ -331,3 +335,50 @@ def csr_band_k(n, ia, ja, a, kmax=50, frac=0.95):
     if rc:
         raise SpikeError("spike_csr_band_k failed (%d)" % rc)
     return k.value, f.value
+
+
+def permute_csr(A, rowp, colp):
+    """device MatPermute on a scipy CSR matrix (host arrays in and out): (ib, jb, b)"""
+    n = A.shape[0]
+    ia = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    ja = np.ascontiguousarray(A.indices, dtype=np.int64)
+    a = np.ascontiguousarray(A.data, dtype=np.float64)
+    rowp = np.ascontiguousarray(rowp, dtype=np.int64)
+    colp = np.ascontiguousarray(colp, dtype=np.int64)
+    ib = np.zeros(n + 1, dtype=np.int64)
+    jb = np.zeros(len(ja), dtype=np.int64)
+    b = np.zeros(len(ja))
+    rc = lib().spike_permute_csr(n, ia.ctypes.data_as(iptr), ja.ctypes.data_as(iptr), a.ctypes.data_as(dptr), rowp.ctypes.data_as(iptr),
+                                 colp.ctypes.data_as(iptr), ib.ctypes.data_as(iptr), jb.ctypes.data_as(iptr), b.ctypes.data_as(dptr))
+    if rc:
+        raise SpikeError("spike_permute_csr failed (%d)" % rc)
+    return ib, jb, b
+
+
+def permute_vec(x, idx, inverse=False):
+    """device VecPermute, out of place: numpy arrays (staged) or torch CUDA tensors (in place on the device)"""
+    n = len(x)
+    if _is_torch(x):
+        import torch
+        y = torch.empty_like(x)
+        rc = lib().spike_permute_vec(n, C.c_void_p(idx.data_ptr()), int(inverse), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 1)
+    else:
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        y = np.empty_like(x)
+        rc = lib().spike_permute_vec(n, C.c_void_p(idx.ctypes.data), int(inverse), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), 0)
+    if rc:
+        raise SpikeError("spike_permute_vec failed (%d)" % rc)
+    return y
+
+
+def awbm_device(n, ia, ja, a):
+    """AWBM with the greedy phases on the device: (perm, [rounds of phase 1, rounds of phase 3])"""
+    ia = np.ascontiguousarray(ia, dtype=np.int64)
+    ja = np.ascontiguousarray(ja, dtype=np.int64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    perm = np.zeros(n, dtype=np.int64)
+    rounds = (C.c_int * 2)(0, 0)
+    rc = lib().spike_awbm_device(n, ia.ctypes.data_as(iptr), ja.ctypes.data_as(iptr), a.ctypes.data_as(dptr), perm.ctypes.data_as(iptr), rounds)
+    if rc:
+        raise SpikeError("spike_awbm_device failed (%d)" % rc)
+    return perm, [rounds[0], rounds[1]]

@@ -175,6 +175,24 @@ PetscErrorCode MatPermute(Mat A, IS rowp, IS colp, Mat *B)
 {
     const PetscInt n = A->n;
     if (rowp->n != n || colp->n != n) return seterr(PETSC_ERR_ARG_SIZ, "MatPermute: permutation length");
+    /* -mat_permute_device 0|1 (default 1): the gather + per-row sort on the GPU when one is present (libspike_mi355:
+       spike_permute_csr; same arrays bit for bit); small matrices and device-less hosts take the loop below */
+    {
+        int usedev = 1;
+        char v[16];
+        if (opt_str(NULL, "mat_permute_device", v, sizeof v)) usedev = atoi(v) != 0;
+        if (usedev && n >= 4096 && spike_device_count() > 0) {
+            const PetscInt nz = A->ia[n];
+            PetscInt *ib = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(n + 1)), *jb = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(nz > 0 ? nz : 1));
+            PetscScalar *bb = (PetscScalar *)malloc(sizeof(PetscScalar) * (size_t)(nz > 0 ? nz : 1));
+            const int rc = (ib && jb && bb) ? spike_permute_csr(n, A->ia, A->ja, A->a, rowp->idx, colp->idx, ib, jb, bb) : -7;
+            PetscErrorCode e = rc == 0 ? MatCreateSeqAIJWithArrays(n, ib, jb, bb, B) : 0;
+            free(ib); free(jb); free(bb);
+            if (rc == 0) return e;
+            if (rc == -1) return seterr(PETSC_ERR_ARG_WRONG, "MatPermute: row / column IS is not a permutation");
+            /* any other failure (no memory, device trouble): the host loop computes the same thing */
+        }
+    }
     PetscInt *icol = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
     for (PetscInt j = 0; j < n; ++j) icol[j] = -1;
     for (PetscInt j = 0; j < n; ++j) {
@@ -272,6 +290,18 @@ PetscErrorCode VecPermute(Vec v, IS is, PetscBool inv)
 {
     if (is->n != v->n) return seterr(PETSC_ERR_ARG_SIZ, "VecPermute: IS length");
     PetscScalar *t = (PetscScalar *)malloc(sizeof(PetscScalar) * (size_t)v->n);
+    /* -vec_permute_device 1 (default 0): the gather on the GPU (spike_permute_vec).  The mirror's vectors live on the host, so
+       this stages them over PCIe and is not faster here; it exists so that the device entry point is exercised by the same
+       callers (src/kspreorder.c:122-127) -- a host with device-resident vectors passes device pointers to it directly */
+    {
+        char o[16];
+        if (opt_str(NULL, "vec_permute_device", o, sizeof o) && atoi(o) != 0 && spike_device_count() > 0 &&
+            spike_permute_vec(v->n, is->idx, inv ? 1 : 0, v->a, t, 0) == 0) {
+            memcpy(v->a, t, sizeof(PetscScalar) * (size_t)v->n);
+            free(t);
+            return 0;
+        }
+    }
     if (!inv) for (PetscInt i = 0; i < v->n; ++i) t[i] = v->a[is->idx[i]];
     else for (PetscInt i = 0; i < v->n; ++i) t[is->idx[i]] = v->a[i];
     memcpy(v->a, t, sizeof(PetscScalar) * (size_t)v->n);
@@ -387,7 +417,12 @@ PetscErrorCode MatGetOrdering_AWBM(Mat A, MatOrderingType type, IS *row, IS *col
     (void)type;
     const PetscInt n = A->n;
     PetscInt *p = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)n);
-    const int rc = spike_awbm(n, A->ia, A->ja, A->a, p, NULL, NULL);
+    /* -mat_awbm_device 0|1 (default 1): the two greedy phases on the GPU when one is present (libspike_mi355:
+       spike_awbm_device, a fixed-point iteration that reproduces the sequential greedy: the SAME matching) */
+    int usedev = 1, rc = -1;
+    { char v[16]; if (opt_str(NULL, "mat_awbm_device", v, sizeof v)) usedev = atoi(v) != 0; }
+    if (usedev && n >= 4096 && spike_device_count() > 0) rc = spike_awbm_device(n, A->ia, A->ja, A->a, p, NULL);
+    if (rc) rc = spike_awbm(n, A->ia, A->ja, A->a, p, NULL, NULL);
     if (rc) { free(p); return seterr(PETSC_ERR_LIB, rc == -2 ? "Column unmatched" : "AWBM failed"); }
     PetscErrorCode e = ISCreateGeneral(n, p, row);
     free(p);

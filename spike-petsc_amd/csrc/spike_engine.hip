@@ -806,7 +806,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     if (h->nranks == 1 && (row0 != 0 || n != n_global)) return fail(h, SPIKE_ERR_ARG, "single rank must own all rows");
     if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "n_local too large");
     SweepCfg cfg;
-    if (!pick_cfg(K, &cfg)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..256)", K);
+    if (!pick_cfg(K, &cfg)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..512)", K);
     (void)hipStreamSynchronize(h->stream);
     free_factors(h);
     TmpPool tmp;
@@ -853,7 +853,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     // multiples of 64 except the end of the last chain, i.e. n.  Whether the spikes really die inside a half is measured
     // below; if not, setup starts over without twisting.
     bool can_twist = h->twist_opt && allow_twist && !cfg.scan && K >= 2 && h->spike_storage &&
-                     (K <= 32 || (n % 16 == 0 && getenv("SPIKE_NO_TRSM") == nullptr)) && getenv("SPIKE_NO_TWIST") == nullptr;
+                     (K <= 32 || (K <= 256 && n % 16 == 0 && getenv("SPIKE_NO_TRSM") == nullptr)) && getenv("SPIKE_NO_TWIST") == nullptr;
     if (h->opt_partitions > 0 && h->subsplit && allow_subsplit && K > 0) {
         // A caller-chosen P may leave most CUs without a chain.  Cut every partition into S chains; the cuts are
         // treated like partition interfaces (truncated coupling), which reproduces the P-partition preconditioner to
@@ -949,7 +949,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(dalloc(&h->dDinv, (size_t)n));
     HIPCHK(dalloc(&h->dY, (size_t)n));
     HIPCHK(dalloc(&h->dTmp, (size_t)n));
-    if (!(cfg.R == 64 && !cfg.scan)) {   // k_pack64 writes every entry of every tile, zeros included
+    if (!(cfg.R == 64 && !cfg.scan && K <= 256)) {   // k_pack64 writes every entry of every tile, zeros included
         HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
         HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
     }
@@ -1170,7 +1170,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(hipStreamSynchronize(st));
             tmp.release(dZ);
         }
-        const bool batched = cfg.R == 64 && !cfg.scan;
+        const bool batched = cfg.R == 64 && !cfg.scan && K <= 256;   // (K > 256: one column per pass through the plain sweeps)
         const int NRB = batched ? sweep_multi_nr(cfg) : 1;
         double *rhsM = rhs, *solM = sol, *midM = h->dY;
         if (batched && !trsm) {

@@ -44,7 +44,7 @@ struct SweepCfg {
     // sweep-time shape of PCApply (0 = the base shape above): the tile layout is independent of how the KP diagonals are
     // dealt to waves, so setup may pick another (DPW, NW, prefetch depth) for the apply sweeps (launch_sweep)
     int sDPW = 0, sNW = 0, sPF = 0;
-    int basePF() const { return R == 4 ? 12 : R == 8 ? 8 : R == 16 ? 4 : 2; }
+    int basePF() const { return R == 4 ? 12 : R == 8 ? 8 : R == 16 ? 4 : (DPW == 64 ? 1 : 2); }
     int KP() const { return scan ? 1 : DPW * NW; }
     int CPW() const { return 64 / R; }
     int64_t tile_doubles() const { return (int64_t)NW * DPW * 64; }

@@ -36,7 +36,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------
 bool pick_cfg(int K, SweepCfg *cfg)
 {
-    if (K < 0 || K > 256) return false;
+    if (K < 0 || K > 512) return false;
+    // 256 < K <= 512 (round 3): supported, not tuned.  64 diagonals per wave, 5..8 waves per chain, one bundle in flight (the
+    // bundle alone is 128 VGPRs); setup takes the generic paths (diagonal-major LU scratch, scalar right-looking
+    // factorisation, spike columns one at a time through the sweep kernels, no twisting)
+    if (K > 256) { *cfg = {64, 64, (K + 63) / 64}; return true; }
     if (K == 1) { *cfg = {64, 2, 1}; cfg->scan = true; }  // tridiagonal: wavefront scan, 56 bytes per row and pass
     else if (K <= 4) *cfg = {4, 4, 1};   // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8
     else if (K <= 8) *cfg = {8, 8, 1};
@@ -165,15 +169,20 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         // The lane's DPW window values are requested back to back and only then consumed: left to itself the compiler
         // (short of registers next to the prefetched bundles) issues read - wait - 2 FMA - read ..., i.e. NLD serial LDS
         // round trips of ~64 cycles each per phase, which made the block step, not HBM, the limit of a lone chain.
-        double xa[DPW];
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) xa[i] = wp[KP - 1 - i];
-        __builtin_amdgcn_sched_barrier(0);
+        // (64 diagonals per wave: in two batches of 32, so that window values + bundle stay inside the register file)
+        constexpr int XB = DPW > 32 ? 32 : DPW;
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            acc0 = fma(t[i].x, xa[2 * i], acc0);       // d = w*DPW + 1 + 2i
-            acc1 = fma(t[i].y, xa[2 * i + 1], acc1);   // d + 1
+        for (int hx = 0; hx < DPW / XB; ++hx) {
+            double xa[XB];
+#pragma unroll
+            for (int i = 0; i < XB; ++i) xa[i] = wp[KP - 1 - (hx * XB + i)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < XB / 2; ++i) {
+                acc0 = fma(t[hx * (XB / 2) + i].x, xa[2 * i], acc0);       // d = w*DPW + 1 + 2i
+                acc1 = fma(t[hx * (XB / 2) + i].y, xa[2 * i + 1], acc1);   // d + 1
+            }
         }
         double acc = acc0 + acc1;
         if (NW > 1) {
@@ -190,15 +199,18 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         double g = tt;
         if (w < NWB) {
             const double *w2p = &W2[c][KP + lr - w * DPW - 1];
-            double xb[DPW];
-#pragma unroll
-            for (int i = 0; i < DPW; ++i) xb[i] = w2p[-i];
-            __builtin_amdgcn_sched_barrier(0);
             double b0 = 0.0, b1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                b0 = fma(t[i].x, xb[2 * i], b0);       // d0 = w*DPW + 1 + 2i
-                b1 = fma(t[i].y, xb[2 * i + 1], b1);
+            for (int hx = 0; hx < DPW / XB; ++hx) {
+                double xb[XB];
+#pragma unroll
+                for (int i = 0; i < XB; ++i) xb[i] = w2p[-(hx * XB + i)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < XB / 2; ++i) {
+                    b0 = fma(t[hx * (XB / 2) + i].x, xb[2 * i], b0);       // d0 = w*DPW + 1 + 2i
+                    b1 = fma(t[hx * (XB / 2) + i].y, xb[2 * i + 1], b1);
+                }
             }
             if (NW > 1) red2[w][lane] = b0 + b1;
             else g = tt - (b0 + b1);
@@ -309,6 +321,15 @@ hipError_t launch_sweep(const SweepCfg &cfg, bool rev, int ngroups, const SweepA
     if (cfg.R == 8) return launch_sweep_t<8, 8, 1, 8>(rev, ngroups, a, st, tag);
     if (cfg.R == 16) return launch_sweep_t<16, 16, 1, 4>(rev, ngroups, a, st, tag);
     if (cfg.R == 32) return launch_sweep_t<32, 32, 1, 2>(rev, ngroups, a, st, tag);
+    if (cfg.DPW == 64) {   // 256 < K <= 512
+        switch (cfg.NW) {
+        case 5: return launch_sweep_t<64, 64, 5, 1>(rev, ngroups, a, st, tag);
+        case 6: return launch_sweep_t<64, 64, 6, 1>(rev, ngroups, a, st, tag);
+        case 7: return launch_sweep_t<64, 64, 7, 1>(rev, ngroups, a, st, tag);
+        case 8: return launch_sweep_t<64, 64, 8, 1>(rev, ngroups, a, st, tag);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (cfg.NW) {
     case 2: return launch_sweep_t<64, 32, 2, 2>(rev, ngroups, a, st, tag);
     case 3: return launch_sweep_t<64, 32, 3, 2>(rev, ngroups, a, st, tag);
@@ -848,7 +869,7 @@ hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t l
 // doubles of the block-band scratch for n local rows (0 when the diagonal-major scratch is used)
 size_t lu_blocks_doubles(int64_t n, int K)
 {
-    if (K <= 32) return 0;
+    if (K <= 32 || K > 256) return 0;   // (K > 256: the generic paths work on the diagonal-major scratch)
     const int KB = lu_kb(K);
     return (size_t)((n + 15) / 16) * (size_t)(2 * KB + 1) * 256;
 }
@@ -1816,7 +1837,7 @@ hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains,
                          unsigned long long *nboost, hipStream_t st)
 {
     if (nchains <= 0) return hipSuccess;
-    if (K <= 8) return launch_factor_generic(lu, ld, K, chains, nchains, boost, nboost, st);
+    if (K <= 8 || K > 256) return launch_factor_generic(lu, ld, K, chains, nchains, boost, nboost, st);
     LuView lv;
     lv.p = lu; lv.ld = ld; lv.K = K; lv.KB = (K + 15) / 16; lv.ntl = K > 32 ? 2 * lv.KB + 1 : 0;
     if (K <= 16) return launch_factor_mfma_t<1, 1>(lv, chains, nchains, boost, nboost, st);
@@ -2206,6 +2227,11 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
     case 16: hipLaunchKernelGGL((k_pack<16>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 32: hipLaunchKernelGGL((k_pack<32>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv); break;
     case 64: {
+        if (K > 256) {   // generic path: diagonal-major scratch, two 64 x 64 squares in LDS (the kernel zero-fills nothing: the
+                         // caller clears the tiles)
+            hipLaunchKernelGGL((k_pack<64>), grid, dim3(64), 0, st, cfg.DPW, cfg.NW, lu, ld, K, chains, groups, Lt, Ut, dinv);
+            break;
+        }
         LuView lv;   // K > 32: the scratch is block-band (launch_band_to_blocks / launch_factor)
         lv.p = const_cast<double *>(lu); lv.ld = ld; lv.K = K; lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;
         hipLaunchKernelGGL(k_pack64, grid, dim3(64), (size_t)16 * (16 * ((K + 15) / 16) + 1) * sizeof(double), st, cfg.DPW, cfg.NW, lv, K,

@@ -309,11 +309,14 @@ def test_full_size_properties(spike, oracle, torch_cuda):
 
 @pytest.mark.parametrize("N,K,P", [(64, 0, 1), (1000, 0, 3), (64, 1, 1), (65, 3, 1), (100, 5, 1), (129, 8, 2), (200, 40, 1),
                                    (300, 100, 1), (1000, 128, 2), (5000, 256, 3), (4097, 33, 4), (777, 17, 3),
-                                   (3000, 200, 2), (2103, 160, 1), (1377, 256, 1)])
+                                   (3000, 200, 2), (2103, 160, 1), (1377, 256, 1),
+                                   (2103, 260, 1), (3000, 300, 2), (4096, 384, 2), (5000, 512, 3), (1100, 450, 1)])
 def test_edge_sizes(spike, oracle, torch_cuda, N, K, P):
     """diagonal matrices (K = 0), a single 64-row block, ragged last blocks, partitions barely longer than K,
     unequal chain lengths (129 rows in 2 partitions: the stored-spike window must not drop the longer chain's tail), wide bands
-    on chains with an odd number of 16-row blocks (the two-steps-per-pass factorisation ends on a single step)."""
+    on chains with an odd number of 16-row blocks (the two-steps-per-pass factorisation ends on a single step), and (round 3)
+    half-bandwidths above 256 -- -pc_banded_kmax is unbounded in the reference (matbanded.c:156): 260 ... 512 take the
+    64-diagonals-per-wave sweeps and the generic setup paths."""
     band = oracle.gen_band(N, K, delta=0.9)
     f = oracle.gen_vec(N)
     sp = spike.Spike(partitions=P).setup_band(band)
@@ -448,3 +451,23 @@ def test_random_shapes_match_oracle(spike, oracle, torch_cuda):
         ref = oracle.Spike(band, sp.info().P_local).apply(f, 1 if variant == "coupled" else 0)
         assert _rel(x, ref) <= 1e-10, (case, N, K, P, delta, variant, _rel(x, ref))
         sp.close()
+
+
+@pytest.mark.parametrize("N,K,P", [(2 ** 15, 384, 4), (2 ** 15, 512, 2)])
+def test_wide_bands_above_256(spike, oracle, torch_cuda, N, K, P):
+    """256 < K <= 512 (supported, not tuned): against the oracle for the caller's partitions, both variants, and the
+    exact-solution round trip on the dominant system"""
+    band = oracle.gen_band(N, K, delta=1.2)
+    f = oracle.gen_vec(N)
+    ref = oracle.Spike(band, P)
+    for variant, vname in ((1, "coupled"), (0, "decoupled")):
+        sp = spike.Spike(partitions=P, variant=vname).setup_band(band)
+        assert _rel(sp.apply(f), ref.apply(f, variant)) <= TOL
+        i = sp.info()
+        assert i.K == K and i.Kp == 64 * ((K + 63) // 64) and i.nboost == ref.nboost
+        sp.close()
+    sp = spike.Spike(partitions=0).setup_band(band)
+    u = np.ones(N)
+    assert np.abs(sp.apply(oracle.band_matvec(band, u)) - u).max() <= 1e-10
+    with pytest.raises(spike.SpikeError):
+        spike.Spike(partitions=1).setup_band(oracle.gen_band(2048, 513, delta=1.2))

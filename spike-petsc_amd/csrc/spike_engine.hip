@@ -554,6 +554,7 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // (N = 8M: K = 2 0.230 -> 0.189 ms, K = 4 0.247 -> 0.195), the wave count first where it does not (N = 4M, K = 4:
     // 8192 chains of 512 rows 0.122 ms, 4096 of 1024 rows 0.152)
     if (cfg.R == 4 && minrows < 1024 && n / 1024 >= target) minrows = 1024;
+    if (const char *e = getenv("SPIKE_AUTO_CHAINS")) { const int64_t t = atoll(e); if (t > 0) { target = t; minrows = 64; } }   // measurement knob
     int64_t byrows = n / minrows;
     int64_t P = target < byrows ? target : byrows;
     if (P > nblk) P = nblk;

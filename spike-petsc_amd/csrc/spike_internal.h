@@ -37,7 +37,7 @@ struct GroupDesc {
 
 // Kernel configuration picked from the half-bandwidth.
 struct SweepCfg {
-    int R;    // rows per block (8,16,32,64)
+    int R;    // rows per block (4,8,16,32,64)
     int DPW;  // diagonals per wave (= tile entries per lane per wave)
     int NW;   // waves per chain
     bool scan = false;  // K = 1: no tiles, one multiplier per row, wavefront scan (k_scan_sweep)

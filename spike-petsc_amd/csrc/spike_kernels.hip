@@ -18,6 +18,8 @@
 //    used once, straight from VGPRs, with the next step's tile already in flight.
 #include "spike_internal.h"
 
+#include <cstdlib>
+
 namespace spike {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -42,7 +44,11 @@ bool pick_cfg(int K, SweepCfg *cfg)
     // factorisation, spike columns one at a time through the sweep kernels, no twisting)
     if (K > 256) { *cfg = {64, 64, (K + 63) / 64}; return true; }
     if (K == 1) { *cfg = {64, 2, 1}; cfg->scan = true; }  // tridiagonal: wavefront scan, 56 bytes per row and pass
-    else if (K <= 4) *cfg = {4, 4, 1};   // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8
+    // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8.  (Round 3 measured a 2-row /
+    // 2-diagonal configuration for K = 2 -- tiles that hold exactly the band, 9 instead of 13 doubles per row and pass, 32
+    // chains per wave: 0.216-0.220 ms per apply at N = 8M against 0.179 for this one, gpurun_out/r3/k2_ab.log: twice the block
+    // steps per row cost more than the bytes saved.  Removed again.)
+    else if (K <= 4) *cfg = {4, 4, 1};
     else if (K <= 8) *cfg = {8, 8, 1};
     else if (K <= 16) *cfg = {16, 16, 1};
     else if (K <= 32) *cfg = {32, 32, 1};

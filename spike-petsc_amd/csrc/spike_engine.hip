@@ -733,6 +733,7 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     if (h->cfg.scan && h->max_chain_rows <= 64 * 64) {
         // tridiagonal chains of at most 4096 rows: both sweeps in one launch, the intermediate vector stays in registers
         a.out = out;
+        if (h->ready && !with_corr && h->dTips1 != nullptr) { a.tipT = h->dTips1; a.tipB = h->dTips1 + (size_t)h->P; }   // for k_couple_small
         rec(true);
         HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, st, tag));
         rec(false);
@@ -1515,7 +1516,8 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     // coupling step (two tiny launches)
     if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
         h->nif_local_all == P - 1 && !h->twisted && h->spike_m1 == h->spike_m)
-        return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st) == hipSuccess
+        return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st,
+                                   /*tips_ready=*/h->cfg.scan && h->max_chain_rows <= 64 * 64) == hipSuccess
                    ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));

@@ -61,6 +61,7 @@ struct SweepArgs {
     const double *corr_top;  // [nchains*K] or null (forward only)
     const double *corr_bot;  // [nchains*K] or null
     int K;
+    double *tipT = nullptr, *tipB = nullptr;   // k_scan_solve (K = 1): also store every chain's first / last solution value here
 };
 
 // One reduced (interface) system between partition "lo" and the partition below it.
@@ -134,8 +135,9 @@ hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc 
                                int64_t ldr = 0);
 hipError_t launch_spike_extent(const double *sol, const ChainDesc *chains, int nchains, int which, double tol_abs,
                                int *extent, hipStream_t st);
+// tips_ready: the chain-end values are already in `tips` (the fused tridiagonal solve stores them): one launch instead of two
 hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
-                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st);
+                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st, bool tips_ready = false);
 // twisted: every chain has ONE window, at its chain-local top (Wf); a vdir = -1 chain takes the next partition's x_t, reversed
 // m1 < m: the window's m1 rows next to the interface in fp64 (Wf / Vf: K x m1 per chain), the other m - m1 rows in fp32
 // (Wf32 / Vf32: K x (m - m1)); launch_spike_split makes the two parts from a full fp64 window (spike_kernels.hip)

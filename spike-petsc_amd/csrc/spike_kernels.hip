@@ -652,7 +652,11 @@ __global__ __launch_bounds__(256) void k_scan_solve(SweepArgs s, const double *c
                 const double x = fma(a[u], carry, b[u]);
                 carry = last_lane(x);
                 const int rl = (sg + u) * 64 + 63 - lane;
-                if (rl < cd.nrows) s.out[cd.row0 + rl] = x;
+                if (rl < cd.nrows) {
+                    s.out[cd.row0 + rl] = x;
+                    // the narrow-band coupling step wants the chain-end values of g BEFORE the corrections touch them
+                    if (s.tipT != nullptr) { if (rl == 0) s.tipT[p] = x; if (rl == cd.nrows - 1) s.tipB[p] = x; }
+                }
             }
         }
     }
@@ -1498,129 +1502,9 @@ static hipError_t launch_factor_mfma_la_t(const LuView &lv, const ChainDesc *cha
     return e;
 }
 
-// Same algorithm with the trailing window left in global memory (L2 / Infinity Cache resident) and updated in place:
-// used when the K x K window (512 KiB at K = 256) does not fit the register file of one CU.
-template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void k_factor_mfma_inplace(LuView lv, const ChainDesc *chains,
-                                                                 double boost, unsigned long long *nboost)
-{
-    constexpr int NT = NW * 64;
-    extern __shared__ double lds[];
-    double *Pd = lds, *Pc = lds + TS, *Pr = lds + TS + KB * TS;
-    double *rd = lds + (2 * KB + 1) * TS;   // 16 reciprocal pivots
-    const ChainDesc cd = chains[blockIdx.x];
-    const int64_t rs = cd.row0;
-    const int np = cd.nrows;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = (np + 15) / 16;
-    unsigned long long nb = 0;
-    auto ldA = [&](int rb, int cb, int row, int col) -> double {
-        const int r = 16 * rb + row, c = 16 * cb + col;
-        if (r >= np || c >= np) return (r == c) ? 1.0 : 0.0;
-        return lu_get(lv, rs, r, c);
-    };
-    // round 2: a tile inside the chain is 2 KiB contiguous in the block-band scratch and (row = (lane>>4)+4q, col = lane&15)
-    // is its element lane + 64 q: whole-tile moves are four coalesced 512-byte accesses with one scalar base address
-    const int64_t rbg0 = rs >> 4;
-    auto tile_inside = [&](int rb, int cb) -> bool {
-        return 16 * (rb + 1) <= np && 16 * (cb + 1) <= np && cb - rb + lv.KB >= 0 && cb - rb + lv.KB < lv.ntl;
-    };
-    auto tile_base = [&](int rb, int cb) -> double * { return lv.p + ((rbg0 + rb) * lv.ntl + (cb - rb + lv.KB)) * 256; };
-    auto load_tile = [&](double(&t)[4], int rb, int cb) {
-        if (tile_inside(rb, cb)) {
-            const double *tp = tile_base(rb, cb) + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = tp[64 * q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = ldA(rb, cb, (lane >> 4) + 4 * q, lane & 15);
-        }
-    };
-    auto store_tile_g = [&](const double(&t)[4], int rb, int cb) {
-        if (tile_inside(rb, cb)) {
-            double *tp = tile_base(rb, cb) + lane;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tp[64 * q] = t[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
-                if (r < np && c < np) lu_put(lv, rs, r, c, t[q]);
-            }
-        }
-    };
-    auto panel_tile = [&](int tile, int s, int &rb, int &cb) -> double * {
-        if (tile == 0) { rb = s; cb = s; return Pd; }
-        if (tile <= KB) { rb = s + tile; cb = s; return Pc + (tile - 1) * TS; }
-        rb = s; cb = s + tile - KB; return Pr + (tile - KB - 1) * TS;
-    };
-    for (int s = 0; s < nblk; ++s) {
-        // panel of step s: scratch -> LDS, a tile per wave at a time
-        for (int tile = w; tile <= 2 * KB; tile += NW) {
-            int rb, cb;
-            double *T = panel_tile(tile, s, rb, cb);
-            double t[4];
-            load_tile(t, rb, cb);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) T[((lane >> 4) + 4 * q) * LDT + (lane & 15)] = t[q];
-        }
-        __syncthreads();
-        if (w == 0) tile_lu_regs(s, Pd, rd, np, boost, nb, lane);
-        __syncthreads();
-        panel_solves<KB, NT>(Pd, Pc, Pr, rd, tid);
-        __syncthreads();
-        // the finished block row / column goes back (whole tiles), then the trailing update of the K x K window in place
-        // in L2: two tiles per wave in flight (8 loads) before their 8 MFMAs and 8 stores
-        for (int tile = w; tile <= 2 * KB; tile += NW) {
-            int rb, cb;
-            const double *T = panel_tile(tile, s, rb, cb);
-            double t[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = T[((lane >> 4) + 4 * q) * LDT + (lane & 15)];
-            store_tile_g(t, rb, cb);
-        }
-        // Software-pipelined: the loads of the NEXT pair of tiles are issued before the MFMAs and stores of the current
-        // pair.  Vector-memory operations complete in order, so a wave that issues load - MFMA - store - load ... waits for
-        // its own previous stores (a full L2 write round trip) before every load; with the loads ahead of the stores the
-        // wait for them (vmcnt(8)) leaves the stores in flight.
-        auto tile_on = [&](int t) -> bool {
-            const int I = t / KB + 1, J = t % KB + 1;
-            return t < KB * KB && 16 * (s + I) < np && 16 * (s + J) < np;
-        };
-        auto tile_load = [&](int t, double(&a)[4]) { if (tile_on(t)) load_tile(a, s + t / KB + 1, s + t % KB + 1); };
-        auto tile_update_store = [&](int t, double(&a)[4]) {
-            if (!tile_on(t)) return;
-            const int I = t / KB + 1, J = t % KB + 1;
-            v4d acc = {a[0], a[1], a[2], a[3]};
-            const double *Lp = Pc + (I - 1) * TS + (lane & 15) * LDT + (lane >> 4);
-            const double *Up = Pr + (J - 1) * TS + (lane >> 4) * LDT + (lane & 15);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[4 * q], Up[4 * q * LDT], acc, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = acc[q];
-            store_tile_g(a, s + I, s + J);
-        };
-        double pa0[4], pa1[4], pb0[4], pb1[4];
-        tile_load(w, pa0);
-        tile_load(w + NW, pa1);
-        for (int t0 = w; t0 < KB * KB; t0 += 4 * NW) {
-            tile_load(t0 + 2 * NW, pb0);
-            tile_load(t0 + 3 * NW, pb1);
-            tile_update_store(t0, pa0);
-            tile_update_store(t0 + NW, pa1);
-            tile_load(t0 + 4 * NW, pa0);
-            tile_load(t0 + 5 * NW, pa1);
-            tile_update_store(t0 + 2 * NW, pb0);
-            tile_update_store(t0 + 3 * NW, pb1);
-        }
-        __syncthreads();
-    }
-    if (lane == 0 && w == 0 && nb) atomicAdd(nboost, nb);
-}
-
-// k_factor_mfma_inplace2 (round 2): the same in-place algorithm, TWO block steps per pass over the window.
-// k_factor_mfma_inplace reads and writes the whole K x K window (512 KiB per chain at K = 256: 256 chains = 128 MiB, which
+// (The first in-place kernel -- one block step per pass over the window, 65 ms at K = 256 -- was removed in round 3; its
+// successor below does two steps per pass.)
+// That first kernel read and wrote the whole K x K window (512 KiB per chain at K = 256: 256 chains = 128 MiB, which
 // no L2 holds) once per 16-column step: 63 us per step of which ~53 us are that pass -- the kernel moves ~8 TB/s through
 // the memory side and is bound by it, not by its 256 MFMA tiles.  Here panel s is factored as before, then only the NEXT
 // panel (block row / column s+1: 2 KB + 1 tiles) is brought up to date and factored out of a second LDS buffer, and the
@@ -1808,20 +1692,6 @@ static hipError_t launch_factor_mfma_inplace2_t(const LuView &lv, const ChainDes
 }
 
 template <int KB, int NW>
-static hipError_t launch_factor_mfma_inplace_t(const LuView &lv, const ChainDesc *chains, int nchains,
-                                               double boost, unsigned long long *nboost, hipStream_t st)
-{
-    const size_t shm = ((size_t)(2 * KB + 1) * TS + 16) * sizeof(double);
-    if (shm > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_factor_mfma_inplace<KB, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_factor_mfma_inplace<KB, NW>), dim3(nchains), dim3(NW * 64), shm, st, lv, chains, boost, nboost);
-    return hipGetLastError();
-}
-
-template <int KB, int NW>
 static hipError_t launch_factor_mfma_t(const LuView &lv, const ChainDesc *chains, int nchains, double boost,
                                        unsigned long long *nboost, hipStream_t st)
 {
@@ -1849,15 +1719,8 @@ hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains,
     if (K <= 16) return launch_factor_mfma_t<1, 1>(lv, chains, nchains, boost, nboost, st);
     if (K <= 32) return launch_factor_mfma_t<2, 2>(lv, chains, nchains, boost, nboost, st);
     lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;   // block-band scratch: as wide as the kernels' window
-    static const bool old_schedule = getenv("SPIKE_FACTOR_OLD") != nullptr;   // measurement knob: the round-1 schedule
-    if (old_schedule) {
-        if (K <= 64) return launch_factor_mfma_t<4, 4>(lv, chains, nchains, boost, nboost, st);
-        if (K <= 128) return launch_factor_mfma_t<8, 4>(lv, chains, nchains, boost, nboost, st);
-    }
     if (K <= 64) return launch_factor_mfma_la_t<4, 4>(lv, chains, nchains, boost, nboost, st);
     if (K <= 128) return launch_factor_mfma_la_t<8, 8>(lv, chains, nchains, boost, nboost, st);
-    static const bool one_step = getenv("SPIKE_FACTOR_INPLACE_1") != nullptr;   // measurement knob: one block step per window pass
-    if (one_step) return launch_factor_mfma_inplace_t<16, 8>(lv, chains, nchains, boost, nboost, st);
     return launch_factor_mfma_inplace2_t<16, 8>(lv, chains, nchains, boost, nboost, st);
 }
 
@@ -3525,11 +3388,11 @@ __global__ __launch_bounds__(64) void k_couple_small(int nchains, int K, int m, 
 }
 
 hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
-                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st)
+                               const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st, bool tips_ready)
 {
     if (nchains <= 0 || K < 1 || K > 8) return hipErrorInvalidValue;
     double *tipT = tips, *tipB = tips + (size_t)nchains * K;
-    hipLaunchKernelGGL(k_tips_small, dim3((nchains * K + 255) / 256), dim3(256), 0, st, nchains, K, chains, y, tipT, tipB);
+    if (!tips_ready) hipLaunchKernelGGL(k_tips_small, dim3((nchains * K + 255) / 256), dim3(256), 0, st, nchains, K, chains, y, tipT, tipB);
     hipLaunchKernelGGL(k_couple_small, dim3(nchains), dim3(64), 0, st, nchains, K, m, chains, tipT, tipB, WT, ST, VT, Wf, Vf, y);
     return hipGetLastError();
 }

@@ -152,3 +152,32 @@ def test_config5_full_size_eight_ranks_on_one_gpu(spike, oracle):
     for q in res:
         assert q["P"] == Pl and q["Pg"] == G * Pl and q["nranks"] == G and q["n"] == n_rank and q["nboost"] == 0
         assert q["chains"] >= Pl and q["chains"] % Pl == 0
+
+
+@pytest.mark.parametrize("P", [8, 64])
+def test_headline_size_with_the_survey_partition_counts(spike, oracle, P):
+    """SURVEY.md 8d names P = 8 G and 64 G for the headline (N = 4 2^20, K = 128).  A caller-chosen P is honoured -- the
+    preconditioner is P-defined -- but swept as many chains (verified cuts, twisted pairs).  Full size: size-independent
+    properties; the P-partition preconditioner itself is pinned on a slice the oracle can factor (same rows per partition)."""
+    import torch
+    N, K = 4 * 2 ** 20, 128
+    band = spike.gen_band_device(N, K, seed=12345, delta=1.2)
+    sp = spike.Spike(partitions=P, variant="coupled").setup_band(band)
+    i = sp.info()
+    assert i.P_local == P and i.chains_local % P == 0 and i.chains_local >= 128 and i.passes == 1 and i.nboost == 0
+    u = torch.ones(N, dtype=torch.float64, device="cuda")
+    b = sp.matvec(u)
+    x = sp.apply(b)
+    assert float((x - u).abs().max()) <= 1e-10
+    v = torch.from_numpy(oracle.gen_vec(N)).cuda()
+    bv = sp.matvec(v)
+    xv = sp.apply(bv)
+    assert float((sp.matvec(xv) - bv).norm() / bv.norm()) <= 1e-12
+    assert float((sp.apply(b + 3.0 * bv) - (x + 3.0 * xv)).abs().max()) <= 1e-9
+    del band
+    # the oracle's partitioned preconditioner on 2 partitions (P = 64: of the same length as above)
+    n = 2 * (N // P) if P == 64 else 2 ** 16
+    bs = oracle.gen_band(n, K, seed=12345, delta=1.2)
+    f = oracle.gen_vec(n)
+    sps = spike.Spike(partitions=2).setup_band(bs)
+    assert _rel(sps.apply(f), oracle.Spike(bs, 2).apply(f, 1)) <= 1e-10

@@ -132,6 +132,7 @@ struct spike_handle_s {
     // of the result itself, nine below the 1e-10 parity bar -- for 15 % fewer spike rows (1408 -> 1216 at K = 128).
     double spike_tol = 1e-13;
     int spike_fp32 = 1;         // 1 = the far part of every stored spike (entries below 2^-28 of the peak) is kept in fp32
+    int iface_matrix = 1;       // 1 = one-stage interface solves [x_b; x_t] = M [g_b; g_t] (k_iface_apply_m), 0 = the three staged mat-vecs
     int twist_opt = 1;          // 1 = twisted (two-ended) factorisation of chain PAIRS where setup finds it applicable, 0 = never
     hipStream_t stream = nullptr;
     int overlap = 1;            // multi-rank apply: exchange + rank-boundary interfaces on a second stream beside the local coupling work
@@ -155,6 +156,10 @@ struct spike_handle_s {
     std::vector<ChainDesc> chainsV;   // the chains with the identity vector map (setup works in factor space); == chains unless twisted
     ChainDesc *dChainsV = nullptr;    // device copy (aliases dChains unless twisted)
     IfaceDesc *dIfsSeam = nullptr;    // one per pair: the seam system on the intermediate vector, solved in place
+    // one-stage form of the interface solves (option iface_form = matrix): M^T per interface / seam (2K x 2K), descriptors
+    // whose WT points at it; the seam's inputs come from a staging copy of the chains' last K forward results
+    double *dIfM = nullptr, *dSeamM = nullptr, *dSeamStage = nullptr;
+    IfaceDesc *dIfsM = nullptr, *dIfsMInt = nullptr, *dIfsSeamM = nullptr;
     double *dSeamWT = nullptr, *dSeamVT = nullptr, *dSeamST = nullptr;
     int nseam = 0;
     SweepCfg cfg{64, 32, 1};
@@ -347,6 +352,7 @@ static void free_factors(spike_handle h)
     F(h->dWt); F(h->dVb); F(h->dWT); F(h->dVT); F(h->dST); F(h->dBT); F(h->dCT); F(h->dCorrTop); F(h->dCorrBot);
     F(h->dWf32); F(h->dVf32); h->spike_m1 = 0;
     F(h->dTips1); F(h->dWf); F(h->dVf); F(h->dXb); F(h->dXt); F(h->dIfsFast); F(h->dIfsInt); F(h->dIfsFastInt); h->spike_m = 0; h->nif_int = 0;
+    F(h->dIfM); F(h->dSeamM); F(h->dSeamStage); F(h->dIfsM); F(h->dIfsMInt); F(h->dIfsSeamM);
     F(h->dChainsV); F(h->dIfsSeam); F(h->dSeamWT); F(h->dSeamVT); F(h->dSeamST); h->nseam = 0; h->twisted = false; h->chainsV.clear();
     F(h->dAt); F(h->dAtOp); F(h->dStageX); F(h->dStageY);
     F(h->dSend); F(h->dRecv); F(h->dXh); F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
@@ -439,6 +445,11 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "spike_tol") h->spike_tol = atof(val);
     else if (k == "twist") h->twist_opt = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_fp32") h->spike_fp32 = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "iface_form") {
+        if (v == "matrix" || v == "1") h->iface_matrix = 1;
+        else if (v == "staged" || v == "0") h->iface_matrix = 0;
+        else return fail(h, SPIKE_ERR_ARG, "iface_form is 'matrix' or 'staged'");
+    }
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
@@ -714,6 +725,7 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     const ChainDesc *base_chains = h->ready ? h->dChains : h->dChainsV;
     a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : base_chains; a.nchains = h->P; a.K = h->K;
     a.tiles = h->dLt; a.in = in; a.out = h->dY; a.dinv = h->dDinv;
+    if (h->twisted && h->ready && !sub && h->dIfsSeamM) a.seam = h->dSeamStage;
     a.corr_top = with_corr ? h->dCorrTop : nullptr;
     a.corr_bot = with_corr ? h->dCorrBot : nullptr;
     hipStream_t st = h->stream;
@@ -745,7 +757,10 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     rec(false);
     // twisted: both halves of every diagonal block have swept inward; their seam systems (2K x 2K, exact) are solved in
     // place on the intermediate vector, then both halves sweep outward
-    if (h->twisted && h->ready && !sub) HIPCHK(launch_iface_apply(h->K, h->nseam, h->dIfsSeam, h->dY, st));
+    if (h->twisted && h->ready && !sub) {
+        if (h->dIfsSeamM) HIPCHK(launch_iface_apply_m(h->K, h->nseam, h->dIfsSeamM, h->dY, st));   // inputs from the staging copy
+        else HIPCHK(launch_iface_apply(h->K, h->nseam, h->dIfsSeam, h->dY, st));
+    }
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
@@ -1250,6 +1265,21 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 }
             }
         }
+        // one-stage form of `count` interface systems (k_iface_apply_m): M^T from the column-major WT, VT, ST of k_iface_setup
+        auto build_m = [&](int count, const double *WTa, const double *VTa, const double *STa, double **MTout) -> int {
+            *MTout = nullptr;
+            if (count <= 0) return SPIKE_OK;
+            double *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;
+            HIPCHK(tmp.alloc(&P1, (size_t)count * kk)); HIPCHK(tmp.alloc(&P2, (size_t)count * kk)); HIPCHK(tmp.alloc(&P3, (size_t)count * kk));
+            HIPCHK(dalloc(MTout, (size_t)count * 4 * kk));
+            HIPCHK(launch_gemm_kk(K, count, WTa, (int64_t)kk, STa, (int64_t)kk, P1, (int64_t)kk, st));   // (S^-1 W)^T = W^T S^-T
+            HIPCHK(launch_gemm_kk(K, count, STa, (int64_t)kk, VTa, (int64_t)kk, P2, (int64_t)kk, st));   // (V S^-1)^T = S^-T V^T
+            HIPCHK(launch_gemm_kk(K, count, P1, (int64_t)kk, VTa, (int64_t)kk, P3, (int64_t)kk, st));    // (V S^-1 W)^T
+            HIPCHK(launch_build_iface_m(K, count, STa, P1, P2, P3, *MTout, st));
+            HIPCHK(hipStreamSynchronize(st));
+            tmp.release(P1); tmp.release(P2); tmp.release(P3);
+            return SPIKE_OK;
+        };
         // ---- twisted: the seam systems.  With zeta = the corrected forward result at a chain's last K rows,
         //   zeta_a + Tb_a J Gb_b zeta_b = y_a,   zeta_b + Tb_b J Gb_a zeta_a = y_b      (a = top half, b = bottom half, J = reversal)
         // -- the shape of a SPIKE interface system (W = Tb_a J Gb_b, V = Tb_b J Gb_a, S = I - W V), so the interface kernels
@@ -1292,6 +1322,20 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             HIPCHK(upload(h, h->dIfsSeam, sm.data(), sizeof(IfaceDesc) * npairs, st));
             HIPCHK(hipStreamSynchronize(st));
             h->nseam = npairs;
+            if (h->iface_matrix && K >= 32) {   // (narrower: 2K outputs do not fill a workgroup, the staged kernel is as fast -- measured K = 8)
+                if ((rc = build_m(npairs, h->dSeamWT, h->dSeamVT, h->dSeamST, &h->dSeamM))) return rc;
+                HIPCHK(dalloc(&h->dSeamStage, (size_t)P * K));
+                HIPCHK(hipMemsetAsync(h->dSeamStage, 0, sizeof(double) * P * K, st));
+                std::vector<IfaceDesc> smm(sm);
+                for (int t = 0; t < npairs; ++t) {
+                    smm[t].WT = h->dSeamM + (size_t)t * 4 * kk; smm[t].ST = smm[t].VT = nullptr;
+                    smm[t].gt = h->dSeamStage + (size_t)(2 * t) * K;       // staged by the forward launch (SweepArgs::seam)
+                    smm[t].gb = h->dSeamStage + (size_t)(2 * t + 1) * K;
+                }
+                HIPCHK(dalloc(&h->dIfsSeamM, (size_t)npairs));
+                HIPCHK(upload(h, h->dIfsSeamM, smm.data(), sizeof(IfaceDesc) * npairs, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
             mark("seam systems");
         }
         h->spike_m = m;
@@ -1440,6 +1484,20 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 HIPCHK(upload(h, h->dIfsFastInt, fi.data(), sizeof(IfaceDesc) * fi.size(), st));
                 HIPCHK(hipStreamSynchronize(st));
             }
+            if (h->iface_matrix && K >= 32 && nif > 0) {   // one-stage form of the same systems
+                if ((rc = build_m(nif, h->dWT, h->dVT, h->dST, &h->dIfM))) return rc;
+                std::vector<IfaceDesc> fm(ff);
+                for (int i = 0; i < nif; ++i) { fm[i].WT = h->dIfM + (size_t)i * 4 * kk; fm[i].ST = fm[i].VT = nullptr; }
+                HIPCHK(dalloc(&h->dIfsM, (size_t)nif));
+                HIPCHK(upload(h, h->dIfsM, fm.data(), sizeof(IfaceDesc) * nif, st));
+                if (h->nif_int > 0) {
+                    std::vector<IfaceDesc> fi;
+                    for (int i : internal) fi.push_back(fm[i]);
+                    HIPCHK(dalloc(&h->dIfsMInt, fi.size()));
+                    HIPCHK(upload(h, h->dIfsMInt, fi.data(), sizeof(IfaceDesc) * fi.size(), st));
+                }
+                HIPCHK(hipStreamSynchronize(st));
+            }
         }
         HIPCHK(hipStreamSynchronize(st));
     }
@@ -1476,7 +1534,12 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     // interfaces: [0, nloc) lie between two chains of this rank, [nloc, nif) are shared with the neighbouring ranks and
     // need the exchanged tips ([g_top(first chain) | g_bottom(last chain)] = the first and last K entries of y)
     const int nloc = multi ? h->nif_local_all : nif, nedge = nif - nloc;
-    const IfaceDesc *ifs = h->spike_m > 0 ? (coupled ? h->dIfsFast : h->dIfsFastInt) : (coupled ? h->dIfs : h->dIfsInt);
+    const bool mform = h->spike_m > 0 && (coupled ? h->dIfsM != nullptr : h->dIfsMInt != nullptr);   // one-stage interface solves
+    const IfaceDesc *ifs = mform ? (coupled ? h->dIfsM : h->dIfsMInt)
+                                 : (h->spike_m > 0 ? (coupled ? h->dIfsFast : h->dIfsFastInt) : (coupled ? h->dIfs : h->dIfsInt));
+    auto iface_launch = [&](int count, const IfaceDesc *d, hipStream_t s2) -> hipError_t {
+        return mform ? launch_iface_apply_m(K, count, d, y, s2) : launch_iface_apply(K, count, d, y, s2);
+    };
     // (with spike windows that overlap inside a chain a correction of one chain end can reach the other end's tip rows,
     //  which the exchange stream still reads: serial order then)
     // (twisted: a chain has one window, at its own top, never longer than the chain: no such reach)
@@ -1520,7 +1583,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
                                    /*tips_ready=*/h->cfg.scan && h->max_chain_rows <= 64 * 64) == hipSuccess
                    ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
-    HIPCHK(launch_iface_apply(K, nloc, ifs, y, st));
+    HIPCHK(iface_launch(nloc, ifs, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
         HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0, h->twisted,
                                     h->spike_m1, h->dWf32, h->dVf32));
@@ -1528,7 +1591,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, sx, y, h->n, K, h->dSend);
         HIPCHK(hipGetLastError());
         if ((rc = coll_allgather(h, h->dSend, h->dRecv, (size_t)2 * K, sx))) return rc;
-        HIPCHK(launch_iface_apply(K, nedge, ifs + nloc, y, sx));
+        HIPCHK(iface_launch(nedge, ifs + nloc, sx));
         if (h->spike_m > 0)
             HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2, h->twisted, h->spike_m1,
                                         h->dWf32, h->dVf32));
@@ -1994,7 +2057,7 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
     o->nboost = h->nboost;
     o->factor_bytes = (int64_t)(2 * h->factor_doubles + (size_t)h->n) * 8;
-    o->iface_bytes = ((int64_t)h->nif * (h->spike_m > 0 ? 3 : 5) + (int64_t)h->nseam * 3) * (int64_t)h->K * h->K * 8;
+    o->iface_bytes = ((int64_t)h->nif * (h->spike_m > 0 ? (h->dIfsM ? 4 : 3) : 5) + (int64_t)h->nseam * (h->dIfsSeamM ? 4 : 3)) * (int64_t)h->K * h->K * 8;
     o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;
     o->spike_bytes = (int64_t)(h->twisted ? 1 : 2) * ((int64_t)h->spike_m1 * 8 + (int64_t)(h->spike_m - h->spike_m1) * 4) * (int64_t)h->K * h->P;

@@ -62,6 +62,7 @@ struct SweepArgs {
     const double *corr_bot;  // [nchains*K] or null
     int K;
     double *tipT = nullptr, *tipB = nullptr;   // k_scan_solve (K = 1): also store every chain's first / last solution value here
+    double *seam = nullptr;                    // forward launch of a twisted apply: [nchains*K] staging of every chain's last K results
 };
 
 // One reduced (interface) system between partition "lo" and the partition below it.
@@ -128,6 +129,11 @@ hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, const C
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st);
 hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st);
+// one-stage form: desc.WT = MT (2K x 2K, see spike_kernels.hip); the setup pieces that build it from WT, VT, ST
+hipError_t launch_iface_apply_m(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st);
+hipError_t launch_gemm_kk(int K, int count, const double *A, int64_t sa, const double *B, int64_t sb, double *C, int64_t sc, hipStream_t st);
+hipError_t launch_build_iface_m(int K, int nif, const double *ST, const double *P1T, const double *P2T, const double *P3T, double *MT,
+                                hipStream_t st);
 // stored (decayed) spikes: gather m rows of a spike column, measure what lies outside the window, and the
 // second "pass" of the coupled variant as a dense correction  x -= W x_b(prev) (top m rows), x -= V x_t(next)
 hipError_t launch_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int nchains, int which, int col,

@@ -232,7 +232,12 @@ __global__ __launch_bounds__(NW * 64) void k_sweep(SweepArgs a)
         wr[0] = g;
         wr[WS] = g;
         WAVE_LDS_FENCE();
-        if (act && w == 0) a.out[gi] = REV ? g : g * dv;
+        if (act && w == 0) {
+            a.out[gi] = REV ? g : g * dv;
+            // twisted, forward launch: the last K values of every chain ALSO go to a staging array -- the seam kernel reads
+            // them there and writes the corrected values into the intermediate vector, so its workgroups never race
+            if (!REV && a.seam != nullptr && rl >= cd.nrows - K) a.seam[(int64_t)p * K + (rl - (cd.nrows - K))] = g * dv;
+        }
         pos += R;
     };
 
@@ -2969,6 +2974,115 @@ hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double
     if (per <= 8) hipLaunchKernelGGL(k_iface_apply<8>, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs, g);
     else if (per <= 16) hipLaunchKernelGGL(k_iface_apply<16>, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs, g);
     else hipLaunchKernelGGL(k_iface_apply<0>, dim3(nif), dim3(nt), (size_t)4 * K * sizeof(double), st, K, ifs, g);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// One-stage interface solve (round 3).  k_iface_apply runs three DEPENDENT K x K mat-vecs in one workgroup per interface: a
+// workgroup cannot pull more than ~50 GB/s through its CU, so 3 K^2 8 bytes take >= 8 us at K = 128 however many loads are
+// in flight -- on the critical path of every apply twice (seam, outer interfaces) and a third time behind the tip exchange
+// of a multi-GPU job.  Here the three stages are multiplied out at setup:
+//     [x_b; x_t] = M [g_b; g_t],   M = [[I + V S^-1 W, -V S^-1], [-S^-1 W, S^-1]]     (2K x 2K)
+// The rows of M are independent, so an interface is dealt to 2K/64 workgroups (64 outputs each): 4/3 of the bytes, spread
+// over four CUs, one stage.  MT = M^T row-major (MT[c 2K + a] = M[a][c]): consecutive lanes read consecutive addresses.
+// Desc: WT = MT; gb / gt (+ offsets) as k_iface_apply; xb_out / xt_out.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_iface_apply_m(int K, const IfaceDesc *ifs, const double *g)
+{
+    extern __shared__ double shm[];
+    double *g2 = shm;                 // [g_b | g_t], 2K
+    double *red = shm + 2 * K;        // 256 partial sums
+    const IfaceDesc d = ifs[blockIdx.x];
+    const int tid = threadIdx.x, K2 = 2 * K;
+    const int nout = K2 < 64 ? K2 : 64;               // outputs of this workgroup
+    const int a0 = blockIdx.y * 64;
+    const double *pgb = d.gb != nullptr ? d.gb : g + d.gb_off, *pgt = d.gt != nullptr ? d.gt : g + d.gt_off;
+    for (int t = tid; t < K2; t += 256) g2[t] = t < K ? pgb[t] : pgt[t - K];
+    __syncthreads();
+    const int al = tid % nout, part = tid / nout, nparts = 256 / nout;
+    const int a = a0 + al;
+    double acc = 0.0;
+    if (a < K2 && part < nparts) {
+        const double *col = d.WT + a;
+#pragma unroll 8
+        for (int c = part; c < K2; c += nparts) acc = fma(col[(int64_t)c * K2], g2[c], acc);
+    }
+    red[tid] = (part < nparts) ? acc : 0.0;
+    __syncthreads();
+    if (tid < nout && a0 + tid < K2) {
+        double s = 0.0;
+        for (int q = 0; q < nparts; ++q) s += red[q * nout + tid];
+        const int o = a0 + tid;
+        if (o < K) { if (d.xb_out != nullptr) d.xb_out[o] = s; }
+        else if (d.xt_out != nullptr) d.xt_out[o - K] = s;
+    }
+}
+
+hipError_t launch_iface_apply_m(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st)
+{
+    if (nif <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_iface_apply_m, dim3(nif, (2 * K + 63) / 64), dim3(256), (size_t)(2 * K + 256) * sizeof(double), st, K, ifs, g);
+    return hipGetLastError();
+}
+
+// batched C_i = A_i B_i for row-major K x K matrices on v_mfma_f64_16x16x4 (setup: the products that make up M).  A wave owns
+// one 16 x 16 tile of C; lane maps: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], C/D: col = l&15, row = (l>>4) + 4 reg.
+__global__ __launch_bounds__(256) void k_gemm_kk(int K, const double *A, int64_t sa, const double *B, int64_t sb, double *C, int64_t sc)
+{
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = (blockIdx.x * 4 + w) * 16;
+    if (j0 >= K) return;
+    const double *a = A + (int64_t)blockIdx.z * sa, *b = B + (int64_t)blockIdx.z * sb;
+    double *c = C + (int64_t)blockIdx.z * sc;
+    v4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int ai = i0 + li, bj = j0 + li;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + lk;
+        const double av = (ai < K && k < K) ? a[(int64_t)ai * K + k] : 0.0;
+        const double bv = (bj < K && k < K) ? b[(int64_t)k * K + bj] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        if (row < K && col < K) c[(int64_t)row * K + col] = acc[r];
+    }
+}
+
+hipError_t launch_gemm_kk(int K, int count, const double *A, int64_t sa, const double *B, int64_t sb, double *C, int64_t sc, hipStream_t st)
+{
+    if (count <= 0 || K <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gemm_kk, dim3((K + 63) / 64, (K + 15) / 16, count), dim3(256), 0, st, K, A, sa, B, sb, C, sc);
+    return hipGetLastError();
+}
+
+// MT (2K x 2K row-major, = M^T) from ST (S^-T, i.e. the column-major S^-1 of k_iface_setup) and the products
+// P1T = WT ST = (S^-1 W)^T, P2T = ST VT = (V S^-1)^T, P3T = P1T VT = (V S^-1 W)^T
+__global__ __launch_bounds__(256) void k_build_iface_m(int K, const double *ST, const double *P1T, const double *P2T, const double *P3T,
+                                                       double *MT)
+{
+    const int64_t kk = (int64_t)K * K, f = blockIdx.y;
+    const int K2 = 2 * K;
+    const double *st = ST + f * kk, *p1 = P1T + f * kk, *p2 = P2T + f * kk, *p3 = P3T + f * kk;
+    double *m = MT + f * 4 * kk;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 4 * kk; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t / K2), a = (int)(t % K2);
+        double v;
+        if (c < K) v = a < K ? ((a == c ? 1.0 : 0.0) + p3[(int64_t)c * K + a]) : -p1[(int64_t)c * K + (a - K)];
+        else v = a < K ? -p2[(int64_t)(c - K) * K + a] : st[(int64_t)(c - K) * K + (a - K)];
+        m[t] = v;
+    }
+}
+
+hipError_t launch_build_iface_m(int K, int nif, const double *ST, const double *P1T, const double *P2T, const double *P3T, double *MT,
+                                hipStream_t st)
+{
+    if (nif <= 0 || K <= 0) return hipSuccess;
+    int gx = (int)((4 * (int64_t)K * K + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_build_iface_m, dim3(gx, nif), dim3(256), 0, st, K, ST, P1T, P2T, P3T, MT);
     return hipGetLastError();
 }
 

@@ -171,3 +171,19 @@ def test_fp32_spike_tail_changes_nothing_visible(spike, oracle, N, K, P, twist):
     assert float((xb - xc).norm() / xc.norm()) <= 1e-15
     u = torch.ones(N, dtype=torch.float64, device="cuda")
     assert float((a.apply(a.matvec(u)) - u).abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize("N,K,P,twist", [(2 ** 17, 128, 8, "auto"), (2 ** 17, 128, 8, "off"), (2 ** 16, 100, 3, "auto"), (2 ** 16, 8, 16, "auto"),
+                                         (2 ** 16, 3, 5, "off"), (2 ** 16, 32, 8, "auto"), (2 ** 15, 200, 2, "auto")])
+def test_one_stage_interface_solves_equal_the_staged_ones(spike, oracle, N, K, P, twist):
+    """iface_form = matrix (default): [x_b; x_t] = M [g_b; g_t] with M multiplied out at setup, dealt to 2K/64 workgroups per
+    interface (and for the seams, with the inputs staged by the forward launch); = staged: the three dependent mat-vecs.
+    Same preconditioner: both against the oracle, coupled and decoupled."""
+    band = oracle.gen_band(N, K, delta=1.2)
+    f = oracle.gen_vec(N)
+    ref = oracle.Spike(band, P)
+    for variant, vname in ((1, "coupled"), (0, "decoupled")):
+        xo = ref.apply(f, variant)
+        xm = _mk(spike, P, vname, twist, iface_form="matrix").setup_band(band).apply(f)
+        xs = _mk(spike, P, vname, twist, iface_form="staged").setup_band(band).apply(f)
+        assert _rel(xm, xo) <= TOL and _rel(xs, xo) <= TOL and _rel(xm, xs) <= 1e-12

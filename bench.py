@@ -45,10 +45,10 @@ def pmc_traffic(N, K, world):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
         if d["N"] == N and d["K"] == K and world == 1:
-            return d["traffic_per_pass_bytes"]
+            return d["traffic_per_pass_bytes"], d.get("commit", "unknown")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def host_cores():
@@ -363,9 +363,9 @@ def main():
             "ksp": m["ksp"],
             "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
                          "achieved": m["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": m["achieved"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(m["N"], K, world),
+                         "frac": m["achieved"] / HBM_PEAK_GBPS, "traffic": pmc_traffic(m["N"], K, world)[0],
                          "traffic_source": "static: profiles/pmc_current.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                           "this command, committed; not re-measured in this run)",
+                                           "this command, captured at commit %s; not re-measured in this run)" % pmc_traffic(m["N"], K, world)[1],
                          "alg_bytes_per_pass": m["pass_bytes"], "pass_ms": m["pass_ms"],
                          "measured_read_ceiling_GBps": m["read_ceiling"],
                          "frac_of_measured_ceiling": m["achieved"] / m["read_ceiling"] if m["read_ceiling"] else None},

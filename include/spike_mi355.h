@@ -201,7 +201,8 @@ int spike_gen_band(void *hip_stream, int64_t n_global, int K, uint64_t seed, dou
                    int64_t nrows, double *band_dev, int64_t ld);
 
 /* ---- introspection --------------------------------------------------------------------------- */
-/* the partition count setup picks for partitions = 0 (host logic, needs no device); <0: K unsupported */
+/* the CHAIN count setup picks for partitions = 0 (host logic, needs no device); <0: K unsupported (> 512).  Where the twisted
+ * factorisation applies the chains are paired: spike_info.P_local is then half of it, spike_info.chains_local all of it */
 int spike_auto_partitions(int K, int64_t n_local);
 int spike_get_info(spike_handle h, spike_info *info);
 int spike_view(spike_handle h, char *buf, size_t buflen);

@@ -73,7 +73,8 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(128, 32768) == 11       # short systems: a chain may be as short as two spike windows + a block
     assert L.spike_auto_partitions(128, 524288) == 182     # N/8 rows per GPU of the headline: 182 chains of 2880 rows, not 128 of 4096
     assert L.spike_auto_partitions(32, 2 ** 20) == 512     # BASELINE config 2: a chain keeps >= 64 K rows (measured: 512 chains 0.138 ms, 1024 0.162)
-    assert L.spike_auto_partitions(300, N) < 0             # K > 256 is refused
+    assert L.spike_auto_partitions(300, N) == 256          # 256 < K <= 512 (round 3): 5..8 waves of 64 diagonals, one workgroup per CU
+    assert L.spike_auto_partitions(513, N) < 0             # K > 512 is refused
 
 
 def test_band_rule_32bit_indices_and_last_value_wins(spike, oracle):

@@ -1290,7 +1290,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             int *dFlagS = nullptr;
             HIPCHK(tmp.alloc(&dWs, (size_t)npairs * kk));
             HIPCHK(tmp.alloc(&dVs, (size_t)npairs * kk));
-            HIPCHK(tmp.alloc(&dWorkS, (size_t)npairs * 2 * kk));
+            HIPCHK(tmp.alloc(&dWorkS, iface_setup_work_doubles(K, npairs)));
             HIPCHK(tmp.alloc(&dFlagS, (size_t)npairs));
             HIPCHK(hipMemsetAsync(dFlagS, 0, sizeof(int) * npairs, st));
             HIPCHK(dalloc(&h->dSeamWT, (size_t)npairs * kk));
@@ -1360,7 +1360,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         if (nif > 0) {
         HIPCHK(tmp.alloc(&dWif, (size_t)nif * kk));
         HIPCHK(tmp.alloc(&dVif, (size_t)nif * kk));
-        HIPCHK(tmp.alloc(&dWork, (size_t)nif * 2 * kk));
+        HIPCHK(tmp.alloc(&dWork, iface_setup_work_doubles(K, nif)));
         HIPCHK(tmp.alloc(&dFlag, (size_t)nif));
         HIPCHK(hipMemsetAsync(dFlag, 0, sizeof(int) * nif, st));
         HIPCHK(dalloc(&h->dWT, (size_t)nif * kk));

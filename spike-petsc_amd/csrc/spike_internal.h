@@ -126,6 +126,9 @@ hipError_t launch_coupling_blocks(const double *band, int64_t ld, int K, const C
                                   double *out, hipStream_t st);
 // S = I - W V, inverse by Gauss-Jordan with partial pivoting; W,V row-major K x K per interface in;
 // outputs column-major WT, VT, ST.  flag[i] != 0 when interface i is singular.
+// doubles of work area launch_iface_setup wants for nif systems (128 < K <= 256: the 2 x 2 block scheme keeps S, S^-1, the
+// verification product and the half-size pieces there)
+size_t iface_setup_work_doubles(int K, int nif);
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st);
 hipError_t launch_iface_apply(int K, int nif, const IfaceDesc *ifs, const double *g, hipStream_t st);

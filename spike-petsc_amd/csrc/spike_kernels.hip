@@ -19,6 +19,7 @@
 #include "spike_internal.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace spike {
 
@@ -2843,6 +2844,9 @@ __global__ __launch_bounds__(1024) void k_iface_setup_lds(int K, const double *W
     }
 }
 
+static hipError_t iface_setup_blocked(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
+                                      double *work, int *flag, hipStream_t st);
+
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st)
 {
@@ -2859,6 +2863,21 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
             return hipGetLastError();
         }
     }
+    if (work != nullptr && K > 128 && K <= 256 && getenv("SPIKE_IFACE_UNBLOCKED") == nullptr) {
+        // 2 x 2 blocks through the LDS kernel (the work area holds iface_setup_work_doubles); a zero pivot inside a diagonal block
+        // or a failed verification of any system sends the whole batch to the unblocked kernel below
+        hipError_t e = iface_setup_blocked(K, nif, W, V, WT, VT, ST, work, flag, st);
+        if (e != hipSuccess) return e;
+        std::vector<int> fl((size_t)nif, 0);
+        e = hipMemcpyAsync(fl.data(), flag, sizeof(int) * nif, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        bool ok = true;
+        for (int i = 0; i < nif; ++i) ok = ok && fl[(size_t)i] == 0;
+        if (ok) return hipSuccess;
+        e = hipMemsetAsync(flag, 0, sizeof(int) * nif, st);
+        if (e != hipSuccess) return e;
+    }
     if (work != nullptr) {   // the caller's work area holds 2 K^2 doubles per interface >= K (K+1)
         const size_t lds = ((size_t)2 * K + 16) * sizeof(double) + (16 + 2 * (size_t)K) * sizeof(int);
         hipLaunchKernelGGL(k_iface_setup_lds<true>, dim3(nif), dim3(1024), lds, st, K, W, V, WT, VT, ST, flag, work);
@@ -2867,6 +2886,173 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
     hipLaunchKernelGGL(k_iface_setup, dim3(nif), dim3(256), (size_t)3 * K * sizeof(double), st, K, W, V, WT, VT, ST,
                        work, flag);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// 128 < K <= 256 (round 3): the K x K interface systems through 2 x 2 blocks.  The in-place Gauss-Jordan above keeps a matrix of
+// K <= 128 in LDS (1.4 ms for 255 of them); at K = 256 the matrix lived in L2 and 127 inverses took 11-12 ms -- twice per setup
+// since the seams have systems of their own.  With S = [A B; C D] split at h1 = ceil(K/2):
+//     Ai = A^-1,  X = Ai B,  Y = C Ai,  Sc = D - C X,  Sci = Sc^-1,  Z = -Sci Y,
+//     S^-1 = [Ai - X Z, -X Sci; Z, Sci]
+// -- two inverses of size <= 128 (the LDS kernel, fed with W' = I - A, V' = I so that its S is A) and six products on MFMA.
+// Pivoting is partial INSIDE the two diagonal blocks only, so the result is verified: R = S S^-1 must be the identity to 1e-9
+// in every entry, else (or on a zero pivot) the caller falls back to the unblocked kernel for the whole batch.
+// ------------------------------------------------------------------------------------------
+// C (M x N, ldc) = alpha A (M x Kc, lda) B (Kc x N, ldb) + beta Cin (ldcin; null: 0); batch strides in doubles
+struct GemmArgs {
+    const double *A, *B, *Cin;
+    double *C;
+    int M, N, Kc, lda, ldb, ldc, ldcin;
+    int64_t sa, sb, sc, scin;
+    double alpha, beta;
+};
+__global__ __launch_bounds__(256) void k_gemm_gen(GemmArgs g)
+{
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = (blockIdx.x * 4 + w) * 16;
+    if (j0 >= g.N) return;
+    const double *a = g.A + (int64_t)blockIdx.z * g.sa, *b = g.B + (int64_t)blockIdx.z * g.sb;
+    v4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int ai = i0 + li, bj = j0 + li;
+    for (int k0 = 0; k0 < g.Kc; k0 += 4) {
+        const int k = k0 + lk;
+        const double av = (ai < g.M && k < g.Kc) ? a[(int64_t)ai * g.lda + k] : 0.0;
+        const double bv = (bj < g.N && k < g.Kc) ? b[(int64_t)k * g.ldb + bj] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    double *c = g.C + (int64_t)blockIdx.z * g.sc;
+    const double *ci = g.Cin ? g.Cin + (int64_t)blockIdx.z * g.scin : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        if (row < g.M && col < g.N) {
+            double v = g.alpha * acc[r];
+            if (ci) v += g.beta * ci[(int64_t)row * g.ldcin + col];
+            c[(int64_t)row * g.ldc + col] = v;
+        }
+    }
+}
+static hipError_t gemm_gen(int count, int M, int N, int Kc, double alpha, const double *A, int lda, int64_t sa, const double *B, int ldb,
+                           int64_t sb, double beta, const double *Cin, int ldcin, int64_t scin, double *C, int ldc, int64_t sc,
+                           hipStream_t st)
+{
+    if (count <= 0 || M <= 0 || N <= 0) return hipSuccess;
+    GemmArgs g{A, B, Cin, C, M, N, Kc, lda, ldb, ldc, ldcin, sa, sb, sc, scin, alpha, beta};
+    hipLaunchKernelGGL(k_gemm_gen, dim3((N + 63) / 64, (M + 15) / 16, count), dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+// dst (R x Cc, ldd) = op(src): mode 0 copy, 1 transpose (src is Cc x R), 2 identity minus src, 3 identity
+__global__ void k_block_op(int mode, int R, int Cc, const double *src, int lds_, int64_t ss, double *dst, int ldd, int64_t sd)
+{
+    const double *s0 = src ? src + (int64_t)blockIdx.y * ss : nullptr;
+    double *d0 = dst + (int64_t)blockIdx.y * sd;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < R * Cc; t += gridDim.x * blockDim.x) {
+        const int r = t / Cc, c = t % Cc;
+        double v;
+        if (mode == 0) v = s0[(int64_t)r * lds_ + c];
+        else if (mode == 1) v = s0[(int64_t)c * lds_ + r];
+        else if (mode == 2) v = (r == c ? 1.0 : 0.0) - s0[(int64_t)r * lds_ + c];
+        else v = r == c ? 1.0 : 0.0;
+        d0[(int64_t)r * ldd + c] = v;
+    }
+}
+static hipError_t block_op(int mode, int count, int R, int Cc, const double *src, int lds_, int64_t ss, double *dst, int ldd, int64_t sd,
+                           hipStream_t st)
+{
+    if (count <= 0 || R <= 0 || Cc <= 0) return hipSuccess;
+    int gx = (R * Cc + 255) / 256;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(k_block_op, dim3(gx, count), dim3(256), 0, st, mode, R, Cc, src, lds_, ss, dst, ldd, sd);
+    return hipGetLastError();
+}
+// flag[f] = 1 when some entry of R_f (K x K) differs from the identity by more than tol (or is not a number)
+__global__ void k_check_identity(int K, const double *R, double tol, int *flag)
+{
+    const double *r0 = R + (int64_t)blockIdx.y * K * K;
+    bool bad = false;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < K * K; t += gridDim.x * blockDim.x) {
+        const double d = fabs(r0[t] - ((t / K == t % K) ? 1.0 : 0.0));
+        if (!(d <= tol)) bad = true;
+    }
+    if (bad) atomicExch(&flag[blockIdx.y], 1);
+}
+
+size_t iface_setup_work_doubles(int K, int nif)
+{
+    const size_t kk = (size_t)K * K;
+    if (K <= 128 || K > 256) return (size_t)nif * 2 * kk;   // the unblocked kernels: K (K + 1) per interface
+    return (size_t)nif * 7 * kk;                             // S, S^-1, R + the half-size pieces (12 x <= kk/4 ... rounded up)
+}
+
+static hipError_t iface_setup_blocked(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
+                                      double *work, int *flag, hipStream_t st)
+{
+    const int h1 = (K + 1) / 2, h2 = K - h1;
+    const int64_t kk = (int64_t)K * K, q1 = (int64_t)h1 * h1, q2 = (int64_t)h2 * h2, q12 = (int64_t)h1 * h2;
+    double *S = work, *Si = S + nif * kk, *R = Si + nif * kk;
+    double *p = R + nif * kk;
+    double *Wb = p; p += nif * q1;      // I - A, later I - Sc (sized for the larger block)
+    double *Ib = p; p += nif * q1;      // identities
+    double *T1 = p; p += nif * q1;      // scratch transposes the LDS kernel writes (its WT / VT outputs)
+    double *T2 = p; p += nif * q1;
+    double *ATi = p; p += nif * q1;     // (A^-1)^T, then (Sc^-1)^T
+    double *Ai = p; p += nif * q1;
+    double *Sci = p; p += nif * q2;
+    double *X = p; p += nif * q12;
+    double *Y = p; p += nif * q12;
+    double *Sc = p; p += nif * q2;
+    hipError_t e;
+#define BCHK(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    // S = I - W V; the transposes the apply kernels stream
+    BCHK(block_op(3, nif, K, K, nullptr, 0, 0, Si, K, kk, st));                                    // Si = I (used as Cin)
+    BCHK(gemm_gen(nif, K, K, K, -1.0, W, K, kk, V, K, kk, 1.0, Si, K, kk, S, K, kk, st));
+    BCHK(block_op(1, nif, K, K, W, K, kk, WT, K, kk, st));
+    BCHK(block_op(1, nif, K, K, V, K, kk, VT, K, kk, st));
+    auto invert = [&](int h, const double *blk, int64_t q, double *outT) -> hipError_t {          // outT = (blk^-1)^T, h x h contiguous
+        if ((e = block_op(2, nif, h, h, blk, K, kk, Wb, h, q, st)) != hipSuccess) return e;       // W' = I - blk
+        if ((e = block_op(3, nif, h, h, nullptr, 0, 0, Ib, h, q, st)) != hipSuccess) return e;    // V' = I
+        const int nt = h <= 8 ? 64 : (h <= 32 ? 256 : 1024);
+        const size_t lds = ((size_t)h * (h + 1) + 2 * h + 16) * sizeof(double) + (16 + 2 * (size_t)h) * sizeof(int);
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_iface_setup_lds<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_iface_setup_lds<false>, dim3(nif), dim3(nt), lds, st, h, Wb, Ib, T1, T2, outT, flag, (double *)nullptr);
+        return hipGetLastError();
+    };
+    // Ai = A^-1
+    BCHK(invert(h1, S, q1, ATi));
+    BCHK(block_op(1, nif, h1, h1, ATi, h1, q1, Ai, h1, q1, st));
+    // X = Ai B (h1 x h2), Y = C Ai (h2 x h1), Sc = D - C X
+    BCHK(gemm_gen(nif, h1, h2, h1, 1.0, Ai, h1, q1, S + h1, K, kk, 0.0, nullptr, 0, 0, X, h2, q12, st));
+    BCHK(gemm_gen(nif, h2, h1, h1, 1.0, S + (int64_t)h1 * K, K, kk, Ai, h1, q1, 0.0, nullptr, 0, 0, Y, h1, q12, st));
+    BCHK(gemm_gen(nif, h2, h2, h1, -1.0, S + (int64_t)h1 * K, K, kk, X, h2, q12, 1.0, S + (int64_t)h1 * K + h1, K, kk, Sc, h2, q2, st));
+    // Sci = Sc^-1 (Sc is contiguous h2 x h2: give it to the inverter as a block with leading dimension h2)
+    {
+        if ((e = block_op(2, nif, h2, h2, Sc, h2, q2, Wb, h2, q2, st)) != hipSuccess) return e;
+        if ((e = block_op(3, nif, h2, h2, nullptr, 0, 0, Ib, h2, q2, st)) != hipSuccess) return e;
+        const int nt = h2 <= 8 ? 64 : (h2 <= 32 ? 256 : 1024);
+        const size_t lds = ((size_t)h2 * (h2 + 1) + 2 * h2 + 16) * sizeof(double) + (16 + 2 * (size_t)h2) * sizeof(int);
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_iface_setup_lds<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_iface_setup_lds<false>, dim3(nif), dim3(nt), lds, st, h2, Wb, Ib, T1, T2, ATi, flag, (double *)nullptr);
+        BCHK(hipGetLastError());
+    }
+    BCHK(block_op(1, nif, h2, h2, ATi, h2, q2, Sci, h2, q2, st));
+    // S^-1 = [Ai - X Z, -X Sci; Z, Sci],  Z = -Sci Y
+    BCHK(gemm_gen(nif, h2, h1, h2, -1.0, Sci, h2, q2, Y, h1, q12, 0.0, nullptr, 0, 0, Si + (int64_t)h1 * K, K, kk, st));                  // Z -> bottom left
+    BCHK(gemm_gen(nif, h1, h1, h2, -1.0, X, h2, q12, Si + (int64_t)h1 * K, K, kk, 1.0, Ai, h1, q1, Si, K, kk, st));                       // top left
+    BCHK(gemm_gen(nif, h1, h2, h2, -1.0, X, h2, q12, Sci, h2, q2, 0.0, nullptr, 0, 0, Si + h1, K, kk, st));                              // top right
+    BCHK(block_op(0, nif, h2, h2, Sci, h2, q2, Si + (int64_t)h1 * K + h1, K, kk, st));                                                   // bottom right
+    // verify, then hand out the column-major form
+    BCHK(gemm_gen(nif, K, K, K, 1.0, S, K, kk, Si, K, kk, 0.0, nullptr, 0, 0, R, K, kk, st));
+    hipLaunchKernelGGL(k_check_identity, dim3(16, nif), dim3(256), 0, st, K, R, 1e-9, flag);
+    BCHK(hipGetLastError());
+    BCHK(block_op(1, nif, K, K, Si, K, kk, ST, K, kk, st));
+#undef BCHK
+    return hipSuccess;
 }
 
 // y[a] = sum_c MT[c*K + a] * x[c];  IFT threads = nparts groups of KA lanes, partial sums via LDS.

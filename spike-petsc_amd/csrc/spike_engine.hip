@@ -921,20 +921,36 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(upload(h, h->dChains, h->chains.data(), sizeof(ChainDesc) * P, st));
     HIPCHK(upload(h, h->dGroups, h->groups.data(), sizeof(GroupDesc) * h->groups.size(), st));
     const bool tw = h->twisted;
-    // setup works in FACTOR space: the chains with the identity vector map, and -- twisted -- a copy of the band in which
-    // the bottom halves are stored flipped, so that factorisation, packing and the spike solves run unchanged
+    // setup works in FACTOR space: the chains with the identity vector map for everything that sweeps vectors; what reads the
+    // MATRIX (the LU scratch copy, the coupling blocks of the spike right-hand sides) takes the chains with their map and the
+    // caller's band and mirrors on the fly (band_at / launch_band_to_blocks): no flipped copy of the band is made
     h->dChainsV = h->dChains;
-    const double *bandF = h->dA;
-    int64_t ldF = h->ldA;
-    double *dAv = nullptr;
+    int64_t *dMoff = nullptr;
+    int *dMdir = nullptr;
     if (tw) {
         h->dChainsV = nullptr;
         HIPCHK(dalloc(&h->dChainsV, (size_t)P));
         HIPCHK(upload(h, h->dChainsV, h->chainsV.data(), sizeof(ChainDesc) * P, st));
-        HIPCHK(tmp.alloc(&dAv, (size_t)nd * n));
-        HIPCHK(launch_band_flip(h->dA, h->ldA, K, h->dChains, P, h->max_chain_rows, dAv, n, st));
-        bandF = dAv; ldF = n;
+        if (lu_blocks_doubles(n, K)) {   // per 64-row block: factor-space row i = caller's row moff + mdir i
+            const int64_t nb64 = (n + BLK - 1) / BLK;
+            std::vector<int64_t> moff((size_t)nb64, 0);
+            std::vector<int> mdir((size_t)nb64, 1);
+            for (int p = 0; p < P; ++p) {
+                const ChainDesc &c = h->chains[p];
+                for (int64_t b = c.row0 / BLK; b < (c.row0 + c.nrows + BLK - 1) / BLK; ++b) {
+                    mdir[(size_t)b] = c.vdir;
+                    moff[(size_t)b] = c.vdir > 0 ? c.vec0 - c.row0 : c.vec0 + c.row0;
+                }
+            }
+            HIPCHK(tmp.alloc(&dMoff, (size_t)nb64));
+            HIPCHK(tmp.alloc(&dMdir, (size_t)nb64));
+            HIPCHK(hipMemcpyAsync(dMoff, moff.data(), sizeof(int64_t) * nb64, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dMdir, mdir.data(), sizeof(int) * nb64, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));   // the host vectors go out of scope
+        }
     }
+    const double *bandF = h->dA;   // (the readers below mirror through the chain map)
+    const int64_t ldF = h->ldA;
 
     mark("band copy");
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
@@ -952,8 +968,9 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     double *dLU = nullptr;
     const size_t lu_blk = lu_blocks_doubles(n, K);   // K > 32: block-band scratch (dense 16 x 16 tiles), made in one transposing pass
     HIPCHK(tmp.alloc(&dLU, lu_blk ? lu_blk : (size_t)nd * n));
-    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, bandF, ldF, dLU, st));
-    else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), bandF, ldF * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
+    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, h->dA, h->ldA, dLU, st, dMoff, dMdir));
+    else if (tw) HIPCHK(launch_band_flip(h->dA, h->ldA, K, h->dChains, P, h->max_chain_rows, dLU, n, st));   // the scratch copy IS the mirror
+    else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);
     HIPCHK(hipMemsetAsync(dNb, 0, sizeof(unsigned long long), st));
     HIPCHK(launch_factor(dLU, n, K, h->dChainsV, P, boost, dNb, st));
@@ -1097,7 +1114,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                     for (int t = 0; t < 2; ++t) {
                         const int col = t == 0 ? 0 : K - 1;
                         if (t == 1 && K == 1) break;
-                        HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChainsV, P, which, col, rhs, st));
+                        HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChains, P, which, col, rhs, st));
                         if (shallow) HIPCHK(hipMemsetAsync(sol, 0, sizeof(double) * n, st));   // rows outside the probed depth read as zero
                         if ((rc = run_pass(h, rhs, sol, false, shallow ? (which == 0 ? &pTop : &pBot) : nullptr))) return rc;
                         HIPCHK(launch_absmax_diag(sol, n, 0, n, dStat + 2, st));
@@ -1182,7 +1199,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             if (region > (nmax + 63) / 64 * 64) region = (nmax + 63) / 64 * 64;
             double *dZ = nullptr;
             HIPCHK(tmp.alloc(&dZ, spike_trsm_scratch_doubles(K, P, region)));
-            HIPCHK(launch_spike_trsm(dLU, K, m, region, h->dChainsV, P, bandF, ldF, h->dWt, h->dVb, h->dWf, h->dVf,
+            HIPCHK(launch_spike_trsm(dLU, K, m, region, h->dChains, P, bandF, ldF, h->dWt, h->dVb, h->dWf, h->dVf,
                                      dZ, dStat, dStat + 1, st, dTb, dGb, h->dDinv));
             HIPCHK(hipStreamSynchronize(st));
             tmp.release(dZ);
@@ -1200,7 +1217,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             const SubChains *sub = partial ? (which == 0 ? &subTop : &subBot) : nullptr;
             for (int col = 0; col < K; col += NRB) {
                 const int nc = std::min(NRB, K - col);  // a short last batch solves stale columns too; they are not gathered
-                HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChainsV, P, which, col, rhsM, st, nc, n));
+                HIPCHK(launch_tip_rhs(bandF, ldF, K, h->dChains, P, which, col, rhsM, st, nc, n));
                 if (batched) {
                     SweepArgs a;
                     a.groups = sub ? sub->groupsF : h->dGroups; a.chains = sub ? sub->chains : h->dChainsV; a.nchains = P; a.K = K;
@@ -1217,7 +1234,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 if (m > 0) HIPCHK(launch_spike_gather(solM, K, m, h->dChainsV, P, which, col, which == 0 ? h->dWf : h->dVf, dStat, dStat + 1, st, nc, n));
             }
         }
-        if (tw && !lu_blk) HIPCHK(launch_seam_small(dLU, n, K, bandF, ldF, h->dChainsV, P, dTb, dGb, st));   // K <= 32: off the diagonal-major LU scratch
+        if (tw && !lu_blk) HIPCHK(launch_seam_small(dLU, n, K, bandF, ldF, h->dChains, P, dTb, dGb, st));   // K <= 32: off the diagonal-major LU scratch
         if (batched && !trsm) { HIPCHK(hipStreamSynchronize(st)); tmp.release(rhsM); tmp.release(solM); tmp.release(midM); }
         HIPCHK(hipStreamSynchronize(st));
         tmp.release(dLU);

@@ -96,7 +96,9 @@ hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const 
 // K > 32: the LU scratch of launch_factor / launch_pack is the BLOCK-BAND layout (dense 16 x 16 tiles, see spike_kernels.hip)
 // made by launch_band_to_blocks from the diagonal-major band; lu_blocks_doubles = its size (0: diagonal-major scratch)
 size_t lu_blocks_doubles(int64_t n, int K);
-hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st);
+// moff / mdir (per 64-row block, or null): the twisted factorisation's row / diagonal mirror, applied while copying
+hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st,
+                                 const int64_t *moff = nullptr, const int *mdir = nullptr);
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st);
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
@@ -156,7 +158,8 @@ hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchai
 hipError_t launch_spike_split(int K, int m, int m1, int nchains, int near_end, const double *full, double *p64, float *p32,
                               double *max32, hipStream_t st);
 
-// twisted factorisation (setup): dst = the band in factor space (the rows of a vdir = -1 chain reversed, its diagonals mirrored)
+// twisted factorisation (setup, K <= 32): dst = the diagonal-major LU scratch = the band in factor space (the rows of a
+// vdir = -1 chain reversed, its diagonals mirrored); wider bands mirror inside launch_band_to_blocks
 hipError_t launch_band_flip(const double *src, int64_t lds, int K, const ChainDesc *chains, int nchains, int max_rows,
                             double *dst, int64_t ldd, hipStream_t st);
 // K x K matrices of every chain's SEAM end (its last K rows), row-major per chain: Tb = (D^-1 L^-1)_bb B (the forward-swept

@@ -820,8 +820,12 @@ __device__ __forceinline__ void lu_put(const LuView &v, int64_t rs, int r, int c
 
 // diagonal-major band -> block-band scratch; one workgroup per RB 16-row blocks, the strip transposed through LDS.
 // (RB = 2 -- 256-byte reads -- was measured slower: its strip leaves room for two workgroups per CU only)
+// moff / mdir (one entry per 64-row block, or null): factor-space row i is the caller's row moff[i / 64] + mdir[i / 64] i, and a
+// mirrored chain (mdir = -1) has its diagonals mirrored -- the twisted factorisation's flip happens in this (transposing)
+// copy, which reads the band anyway
 template <int RB>
-__global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB, const double *band, int64_t ld, double *T)
+__global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB, const double *band, int64_t ld, double *T,
+                                                        const int64_t *moff, const int *mdir)
 {
     extern __shared__ double strip[];   // 16 RB x (W + 1), W = 16 * NTL + 16 (RB - 1)
     constexpr int RW = 16 * RB;
@@ -837,12 +841,14 @@ __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB
     // loop each load waited for the previous LDS store's slot -- 17 memory round trips per workgroup, 5.0 ms at the headline size
     if (i < n) {
         const int nd = 2 * K + 1;
+        const bool mir = mdir != nullptr && mdir[i >> 6] < 0;
+        const int64_t si = moff != nullptr ? (mir ? moff[i >> 6] - i : moff[i >> 6] + i) : i;
         for (int d0 = sub; d0 < nd; d0 += 8 * NSUB) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int d = d0 + u * NSUB;
-                v[u] = band[(int64_t)(d < nd ? d : nd - 1) * ld + i];
+                const int d = d0 + u * NSUB, dc = d < nd ? d : nd - 1;
+                v[u] = band[(int64_t)(mir ? nd - 1 - dc : dc) * ld + si];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -865,7 +871,8 @@ __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB
 // window width (in 16 x 16 tiles) of the blocked factorisation kernels = half-width of the block-band scratch
 static inline int lu_kb(int K) { return K <= 64 ? 4 : (K <= 128 ? 8 : 16); }
 
-hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st)
+hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st, const int64_t *moff,
+                                 const int *mdir)
 {
     if (n <= 0) return hipSuccess;
     const int KB = lu_kb(K), NTL = 2 * KB + 1;
@@ -877,8 +884,8 @@ hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t l
         if (e != hipSuccess) return e;
     }
     const unsigned nwg = (unsigned)(((n + 15) / 16 + RB - 1) / RB);
-    if (RB == 2) hipLaunchKernelGGL(k_band_to_blocks<2>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T);
-    else hipLaunchKernelGGL(k_band_to_blocks<1>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T);
+    if (RB == 2) hipLaunchKernelGGL(k_band_to_blocks<2>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir);
+    else hipLaunchKernelGGL(k_band_to_blocks<1>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir);
     return hipGetLastError();
 }
 
@@ -2292,6 +2299,13 @@ hipError_t launch_band_matvec_tiled(int64_t n, int K, const double *At, const do
 // B_p(a,b) = A[e-K+a, e+b]  -> band slot d = 2K + b - a   (b <= a)
 // (whether a chain end has a neighbour is the host's knowledge: ChainDesc::flags -- for the bottom half of a twisted
 //  partition "top" is the partition's LAST row and "bottom" the seam, see spike_internal.h)
+// entry (chain-local row rl, diagonal d) of the chain's band in FACTOR space, read from the caller's band (vector space): a
+// vdir = -1 chain is stored with rows reversed and diagonals mirrored (d <-> 2K - d).  Setup's readers of the coupling blocks
+// take the chains WITH their vector map and the natural band, so no flipped copy of the band is ever made.
+__device__ __forceinline__ double band_at(const ChainDesc &cd, const double *band, int64_t ld, int K, int rl, int d)
+{
+    return band[(int64_t)(cd.vdir > 0 ? d : 2 * K - d) * ld + cd.vec0 + (int64_t)cd.vdir * rl];
+}
 __device__ __forceinline__ bool has_top(const ChainDesc &cd) { return (cd.flags & CHAIN_HAS_TOP) != 0; }
 __device__ __forceinline__ bool has_bot(const ChainDesc &cd) { return (cd.flags & CHAIN_HAS_BOT) != 0; }
 
@@ -2305,12 +2319,10 @@ __global__ void k_tip_rhs(const double *band, int64_t ld, int K, const ChainDesc
     for (int a = threadIdx.x; a < K; a += blockDim.x) {
         if (which == 0) {
             if (!has_top(cd)) continue;
-            const int64_t r = cd.row0 + a;
-            rhs[r] = (a <= col) ? band[(int64_t)(col - a) * ld + r] : 0.0;
+            rhs[cd.row0 + a] = (a <= col) ? band_at(cd, band, ld, K, a, col - a) : 0.0;
         } else {
             if (!has_bot(cd)) continue;
-            const int64_t r = cd.row0 + cd.nrows - K + a;
-            rhs[r] = (col <= a) ? band[(int64_t)(2 * K + col - a) * ld + r] : 0.0;
+            rhs[cd.row0 + cd.nrows - K + a] = (col <= a) ? band_at(cd, band, ld, K, cd.nrows - K + a, 2 * K + col - a) : 0.0;
         }
     }
 }
@@ -2352,8 +2364,8 @@ __global__ void k_coupling_blocks(const double *band, int64_t ld, int K, const C
         const int a = t % K, b = t / K;  // column-major: out[b*K + a]
         double v = 0.0;
         if (on) {
-            if (which == 0) { if (a <= b) v = band[(int64_t)(b - a) * ld + cd.row0 + a]; }
-            else { if (b <= a) v = band[(int64_t)(2 * K + b - a) * ld + cd.row0 + cd.nrows - K + a]; }
+            if (which == 0) { if (a <= b) v = band_at(cd, band, ld, K, a, b - a); }
+            else { if (b <= a) v = band_at(cd, band, ld, K, cd.nrows - K + a, 2 * K + b - a); }
         }
         out[(int64_t)p * K * K + t] = v;
     }
@@ -2503,10 +2515,10 @@ __global__ __launch_bounds__(KB == 16 ? 256 : 512) void k_spike_trsm2(TrsmArgs a
             double v = 0.0;
             if (col < K) {
                 if (side == 0) {
-                    if (row < K && row <= col) v = a.band[(int64_t)(col - row) * a.ld + cd.row0 + row];
+                    if (row < K && row <= col) v = band_at(cd, a.band, a.ld, K, row, col - row);
                 } else {
                     const int aa = row - (np - K);
-                    if (aa >= 0 && col <= aa) v = a.band[(int64_t)(2 * K + col - aa) * a.ld + cd.row0 + row];
+                    if (aa >= 0 && col <= aa) v = band_at(cd, a.band, a.ld, K, row, 2 * K + col - aa);
                 }
             }
             t[r] = v;
@@ -3533,7 +3545,7 @@ __global__ __launch_bounds__(64) void k_seam_small(const double *lu, int64_t ld,
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         if (a < K) {
-            double v = (j <= a) ? band[(int64_t)(2 * K + j - a) * ldb + r0 + a] : 0.0;
+            double v = (j <= a) ? band_at(cd, band, ldb, K, cd.nrows - K + a, 2 * K + j - a) : 0.0;
 #pragma unroll
             for (int b = 0; b < 32; ++b)
                 if (b < a) v = fma(-F[a][b], z[b], v);

@@ -132,6 +132,7 @@ struct spike_handle_s {
     // of the result itself, nine below the 1e-10 parity bar -- for 15 % fewer spike rows (1408 -> 1216 at K = 128).
     double spike_tol = 1e-13;
     int spike_fp32 = 1;         // 1 = the far part of every stored spike (entries below 2^-28 of the peak) is kept in fp32
+    int correct_nt = 0;         // workgroup size of k_spike_correct (0 = default; measurement option correct_threads)
     int iface_matrix = 1;       // 1 = one-stage interface solves [x_b; x_t] = M [g_b; g_t] (k_iface_apply_m), 0 = the three staged mat-vecs
     int twist_opt = 1;          // 1 = twisted (two-ended) factorisation of chain PAIRS where setup finds it applicable, 0 = never
     hipStream_t stream = nullptr;
@@ -445,6 +446,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
     else if (k == "spike_tol") h->spike_tol = atof(val);
     else if (k == "twist") h->twist_opt = (v == "off" || v == "0") ? 0 : 1;
     else if (k == "spike_fp32") h->spike_fp32 = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "correct_threads") h->correct_nt = atoi(val);
     else if (k == "iface_form") {
         if (v == "matrix" || v == "1") h->iface_matrix = 1;
         else if (v == "staged" || v == "0") h->iface_matrix = 0;
@@ -1603,7 +1605,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     HIPCHK(iface_launch(nloc, ifs, st));
     if (h->spike_m > 0)   // one pass: y = g - W x_b(prev) - V x_t(next) with the stored (decayed) spikes
         HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, st, multi ? 1 : 0, h->twisted,
-                                    h->spike_m1, h->dWf32, h->dVf32));
+                                    h->spike_m1, h->dWf32, h->dVf32, h->correct_nt));
     if (multi) {
         hipLaunchKernelGGL(k_copy_halo, dim3(1), dim3(64), 0, sx, y, h->n, K, h->dSend);
         HIPCHK(hipGetLastError());
@@ -1611,7 +1613,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
         HIPCHK(iface_launch(nedge, ifs + nloc, sx));
         if (h->spike_m > 0)
             HIPCHK(launch_spike_correct(K, h->spike_m, h->dChains, P, h->dWf, h->dVf, h->dXb, h->dXt, y, sx, 2, h->twisted, h->spike_m1,
-                                        h->dWf32, h->dVf32));
+                                        h->dWf32, h->dVf32, h->correct_nt));
         if (overlap) {
             HIPCHK(hipEventRecord(h->evJoin, sx));
             HIPCHK(hipStreamWaitEvent(st, h->evJoin, 0));

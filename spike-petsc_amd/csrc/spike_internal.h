@@ -154,7 +154,7 @@ hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chain
 // (Wf32 / Vf32: K x (m - m1)); launch_spike_split makes the two parts from a full fp64 window (spike_kernels.hip)
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st, int mode = 0, bool twisted = false,
-                                int m1 = 0, const float *Wf32 = nullptr, const float *Vf32 = nullptr);
+                                int m1 = 0, const float *Wf32 = nullptr, const float *Vf32 = nullptr, int nthreads = 0);
 hipError_t launch_spike_split(int K, int m, int m1, int nchains, int near_end, const double *full, double *p64, float *p32,
                               double *max32, hipStream_t st);
 

@@ -3453,19 +3453,23 @@ __global__ __launch_bounds__(256) void k_spike_correct(int K, SpikeStore sp, con
 
 hipError_t launch_spike_correct(int K, int m, const ChainDesc *chains, int nchains, const double *Wf, const double *Vf,
                                 const double *xb, const double *xt, double *x, hipStream_t st, int mode, bool twisted, int m1,
-                                const float *Wf32, const float *Vf32)
+                                const float *Wf32, const float *Vf32, int nthreads)
 {
     if (nchains <= 0 || K <= 0 || m <= 0) return hipSuccess;
     if (m1 <= 0 || m1 > m || Wf32 == nullptr) m1 = m;
     SpikeStore sp{Wf, Vf, Wf32, Vf32, m, m1};
-    const int nb64 = (m1 + 511) / 512, nb32 = (m - m1 + 1023) / 1024;
+    // workgroup size: 2 rows (fp64 part) / 4 rows (fp32 part) per lane, so nt lanes cover 2 nt / 4 nt rows.  With few chains
+    // (strong scaling: 182 chains, windows of 1216 rows) 256-lane workgroups give 3 unequal workgroups per chain -- 546 on 256
+    // CUs; 128 lanes give 5 (option correct_threads)
+    const int nt = (nthreads == 64 || nthreads == 128 || nthreads == 256) ? nthreads : 128;
+    const int nb64 = (m1 + 2 * nt - 1) / (2 * nt), nb32 = (m - m1 + 4 * nt - 1) / (4 * nt);
     if (twisted) {
         const dim3 grid = mode == 2 ? dim3(nb64 + nb32, 2, 1) : dim3(nb64 + nb32, nchains, 1);
-        hipLaunchKernelGGL(k_spike_correct<true>, grid, dim3(256), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
+        hipLaunchKernelGGL(k_spike_correct<true>, grid, dim3(nt), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
         return hipGetLastError();
     }
     const dim3 grid = mode == 2 ? dim3(nb64 + nb32, 2, 1) : dim3(nb64 + nb32, nchains, 2);
-    hipLaunchKernelGGL(k_spike_correct<false>, grid, dim3(256), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
+    hipLaunchKernelGGL(k_spike_correct<false>, grid, dim3(nt), (size_t)K * sizeof(double), st, K, sp, chains, nchains, xb, xt, x, mode, nb64);
     return hipGetLastError();
 }
 

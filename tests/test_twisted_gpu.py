@@ -187,3 +187,20 @@ def test_one_stage_interface_solves_equal_the_staged_ones(spike, oracle, N, K, P
         xm = _mk(spike, P, vname, twist, iface_form="matrix").setup_band(band).apply(f)
         xs = _mk(spike, P, vname, twist, iface_form="staged").setup_band(band).apply(f)
         assert _rel(xm, xo) <= TOL and _rel(xs, xo) <= TOL and _rel(xm, xs) <= 1e-12
+
+
+@pytest.mark.parametrize("N,K,P,delta", [(2 ** 17, 64, 8, 0.9), (2 ** 16, 16, 8, 0.8), (2 ** 17, 128, 4, 1.0), (2 ** 16, 40, 6, 0.7)])
+def test_weak_dominance_whatever_path_setup_takes(spike, oracle, N, K, P, delta):
+    """not diagonally dominant (delta < 1): spikes decay slowly or not at all, so setup may twist, may fall back to ordinary
+    chains, may undo the sub-split and may re-solve instead of storing spikes -- whichever it measures, the result is the
+    caller's P-partition preconditioner (both variants), and a second setup of the same handle gives the same bits"""
+    band = oracle.gen_band(N, K, delta=delta)
+    f = oracle.gen_vec(N)
+    ref = oracle.Spike(band, P)
+    for variant, vname in ((1, "coupled"), (0, "decoupled")):
+        sp = _mk(spike, P, vname).setup_band(band)
+        x = sp.apply(f)
+        assert _rel(x, ref.apply(f, variant)) <= 1e-9, (vname, sp.view())
+        assert sp.info().nboost == ref.nboost
+        sp.setup_band(band)
+        assert np.array_equal(sp.apply(f), x)

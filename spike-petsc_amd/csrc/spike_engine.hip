@@ -494,6 +494,30 @@ extern "C" int spike_comm_init(spike_handle h, int nranks, int rank, const char 
     ncclUniqueId_ u;
     memcpy(u.internal, id, SPIKE_UNIQUE_ID_BYTES);
     NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    // First contact.  The RCCL entry points are bound with dlsym against prototypes and enum values written out in this file
+    // (no rccl.h at build time): check them once per communicator on known data -- a sum, a maximum and an all-gather whose
+    // results every rank can predict -- so that a library with another ABI fails HERE with a message, not later with wrong tips.
+    {
+        double *d = nullptr;
+        HIPCHK(hipMalloc((void **)&d, sizeof(double) * (size_t)(3 + nranks)));
+        const double mine[3] = {1.0, (double)rank, (double)(rank + 1)};
+        HIPCHK(hipMemcpy(d, mine, sizeof mine, hipMemcpyHostToDevice));
+        int rs = g_rccl.AllReduce(d, d, 1, NCCL_FLOAT64, NCCL_SUM, h->comm, nullptr);
+        int rm = g_rccl.AllReduce(d + 1, d + 1, 1, NCCL_FLOAT64, NCCL_MAX, h->comm, nullptr);
+        int rg = g_rccl.AllGather(d + 2, d + 3, 1, NCCL_FLOAT64, h->comm, nullptr);
+        std::vector<double> got((size_t)(3 + nranks), 0.0);
+        hipError_t he = hipStreamSynchronize(nullptr);
+        if (he == hipSuccess) he = hipMemcpy(got.data(), d, sizeof(double) * (size_t)(3 + nranks), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        bool ok = rs == 0 && rm == 0 && rg == 0 && he == hipSuccess && got[0] == (double)nranks && got[1] == (double)(nranks - 1);
+        for (int r = 0; r < nranks && ok; ++r) ok = got[(size_t)(3 + r)] == (double)(r + 1);
+        if (!ok) {
+            g_rccl.CommDestroy(h->comm);
+            h->comm = nullptr;
+            return fail(h, SPIKE_ERR_COMM, "RCCL self-check failed on rank %d of %d (sum %g, max %g): the loaded librccl does not match the "
+                                           "prototypes / enum values this library binds by name", rank, nranks, got[0], got[1]);
+        }
+    }
     return SPIKE_OK;
 }
 

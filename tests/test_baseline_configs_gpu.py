@@ -175,8 +175,8 @@ def test_headline_size_with_the_survey_partition_counts(spike, oracle, P):
     assert float((sp.matvec(xv) - bv).norm() / bv.norm()) <= 1e-12
     assert float((sp.apply(b + 3.0 * bv) - (x + 3.0 * xv)).abs().max()) <= 1e-9
     del band
-    # the oracle's partitioned preconditioner on 2 partitions (P = 64: of the same length as above)
-    n = 2 * (N // P) if P == 64 else 2 ** 16
+    # the oracle's partitioned preconditioner on a slice it factors in seconds (2 partitions)
+    n = 2 ** 15 if P == 64 else 2 ** 16
     bs = oracle.gen_band(n, K, seed=12345, delta=1.2)
     f = oracle.gen_vec(n)
     sps = spike.Spike(partitions=2).setup_band(bs)

@@ -31,7 +31,7 @@ def _mk(spike, P, variant="coupled", twist="auto", **opts):
 CASES = [
     (2 ** 16, 2, 4), (2 ** 16, 3, 7), (2 ** 16 + 33, 4, 8), (2 ** 17, 8, 16), (2 ** 16, 13, 5), (2 ** 17 + 21, 16, 8), (2 ** 17, 32, 8),
     (2 ** 17, 50, 4), (2 ** 17, 64, 8), (3 * 2 ** 15, 100, 3), (2 ** 18, 128, 8), (2 ** 17, 128, 5), (2 ** 17 + 64 * 7, 128, 3),
-    (2 ** 16, 200, 4), (2 ** 15, 256, 2),
+    (2 ** 15, 200, 4), (2 ** 14, 256, 2),
 ]
 
 
@@ -204,3 +204,17 @@ def test_weak_dominance_whatever_path_setup_takes(spike, oracle, N, K, P, delta)
         assert sp.info().nboost == ref.nboost
         sp.setup_band(band)
         assert np.array_equal(sp.apply(f), x)
+
+
+@pytest.mark.parametrize("N,K,chains", [(16384, 64, 64), (8192, 128, 16), (32768, 16, 256)])
+def test_halves_too_short_for_their_spikes_fall_back(spike, oracle, monkeypatch, N, K, chains):
+    """chains barely longer than a few K (forced through the measurement knob SPIKE_AUTO_CHAINS): the spikes do not die inside
+    a half, setup measures that and starts over with the same chains untwisted -- the result is the truncated-SPIKE
+    preconditioner of that many partitions, as the oracle computes it"""
+    monkeypatch.setenv("SPIKE_AUTO_CHAINS", str(chains))
+    band = oracle.gen_band(N, K, delta=1.2)
+    f = oracle.gen_vec(N)
+    sp = _mk(spike, 0).setup_band(band)
+    i = sp.info()
+    assert "(twisted pairs)" not in sp.view() and i.chains_local == chains == i.P_local
+    assert _rel(sp.apply(f), oracle.Spike(band, chains).apply(f, 1)) <= TOL

@@ -31,7 +31,7 @@ def _mk(spike, P, variant="coupled", twist="auto", **opts):
 CASES = [
     (2 ** 16, 2, 4), (2 ** 16, 3, 7), (2 ** 16 + 33, 4, 8), (2 ** 17, 8, 16), (2 ** 16, 13, 5), (2 ** 17 + 21, 16, 8), (2 ** 17, 32, 8),
     (2 ** 17, 50, 4), (2 ** 17, 64, 8), (3 * 2 ** 15, 100, 3), (2 ** 18, 128, 8), (2 ** 17, 128, 5), (2 ** 17 + 64 * 7, 128, 3),
-    (2 ** 15, 200, 4), (2 ** 14, 256, 2),
+    (2 ** 16, 200, 4), (2 ** 15, 256, 2),
 ]
 
 

@@ -218,16 +218,20 @@ def main():
             dist.broadcast(uid, 0)
             sp.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
         if not warmed[0]:
-            # once per process: a small setup of the same half-bandwidth first, so that setup_s below does not contain the
-            # loading of the code object and the runtime's first-use costs (0.4-0.5 s on a fresh box, none of it setup work)
-            # (a quarter of the local rows, at most 1 M: the allocations of the timed setup are then not the process's first
-            #  large ones either -- on one fresh box the first timed setup took 0.75 s after a 64 K-row warm-up, 0.028 s otherwise)
-            wn = max(64 * 1024, min(1 << 20, (n_local // 4) // 64 * 64))
-            w = S.Spike(partitions=0, variant=args.variant)
-            w.setup_band(S.gen_band_device(wn, K, seed=1, delta=args.delta))
+            # once per process: a setup of the same shape first, so that setup_s below does not contain the loading of the code
+            # object, the runtime's first-use costs (0.4-0.5 s on a fresh box) or its allocator's reaction to a first request of
+            # this size -- none of it setup work.  FULL local size since round 3: after a smaller warm-up (a quarter of the rows)
+            # the first hipMalloc of the timed setup stalled for 0.5-5 s on some boxes at K = 256 (17 GB buffers; three setups in a
+            # row WITHOUT a smaller one before them take 0.084 s each: tools/setup_repeat_k256.py)
+            wn = n_local
+            w = S.Spike(partitions=args.partitions, variant=args.variant)
+            w.set_option("subsplit", args.subsplit)
+            wband = S.gen_band_device(wn, K, seed=1, delta=args.delta)
+            w.setup_band(wband)
             w.apply(torch.ones(wn, dtype=torch.float64, device="cuda"))
             torch.cuda.synchronize()
             w.close()
+            del wband
             warmed[0] = True
         band = S.gen_band_device(N, K, seed=12345, delta=args.delta, row0=r0, nrows=n_local)
         torch.cuda.synchronize()

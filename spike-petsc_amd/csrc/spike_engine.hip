@@ -1174,7 +1174,10 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             }
         }
         if (h->spike_storage) {
-            m = (int)(((int64_t)(extent * 1.06) + 64 + 63) / 64 * 64);  // 2 probed columns -> small margin; verified below
+            // two probed columns per side stand for K: a margin of 6 % + 64 rows, rounded to 64, verified below.  K = 1: the probed
+            // column IS the spike (all chains, both sides), so the window is its measured reach + 8 rows, rounded to 16 -- at the
+            // bench size 64 rows instead of 128: the coupling step of a tridiagonal apply moves half the bytes
+            m = K == 1 ? (int)(((int64_t)extent + 8 + 15) / 16 * 16) : (int)(((int64_t)(extent * 1.06) + 64 + 63) / 64 * 64);
             if (m > nmin) m = nmin;
             // worth it only while the correction stays well below a pass over the factors
             const double corr_bytes = (tw ? 1.0 : 2.0) * m * (double)K * 8.0 * P;

@@ -3295,7 +3295,8 @@ __device__ __forceinline__ void atomic_max_pos(double *addr, double v)
 }
 
 // which = 0: W (rows [0,m) of each chain); which = 1: V (rows [nrows-m, nrows)).  absmax_in = peak magnitude inside the
-// window, absmax_edge = peak over the 32 window rows farthest from the interface (must be ~0 for a decayed spike).
+// window, absmax_edge = peak over the 32 (windows shorter than 128 rows: 8) window rows farthest from the interface (must
+// be ~0 for a decayed spike).
 __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, int m, const ChainDesc *chains, int which,
                                                       int col, double *out, double *absmax_in, double *absmax_edge, int64_t ldr)
 {
@@ -3310,7 +3311,7 @@ __global__ __launch_bounds__(256) void k_spike_gather(const double *sol, int K, 
         out[((int64_t)p * K + col) * m + w] = v;
         mi = fmax(mi, fabs(v));
         const int dist = which == 0 ? w : m - 1 - w;  // distance from the interface, in rows
-        if (dist >= m - 32) mo = fmax(mo, fabs(v));
+        if (dist >= m - (m >= 128 ? 32 : 8)) mo = fmax(mo, fabs(v));   // (the tight windows of K = 1 have 8 rows of margin)
     }
     for (int o = 32; o > 0; o >>= 1) { mi = fmax(mi, __shfl_down(mi, o)); mo = fmax(mo, __shfl_down(mo, o)); }
     // thousands of waves share two words: only touch them when the running maximum would actually grow
@@ -3703,13 +3704,37 @@ __global__ __launch_bounds__(64) void k_couple_small(int nchains, int K, int m, 
     }
 }
 
+// K = 1 (round 3): the same step with everything a lane needs requested up front.  k_couple_small walks through four
+// dependent memory round trips per chain (tips -> 1 x 1 matrices -> spike entries -> y) behind eight workgroup barriers;
+// for a tridiagonal system every operand's address is known at launch, so one lane = one (chain end, window row) loads its
+// two tips, the three scalars of its interface, its spike entry and its y entry at once, solves the 1 x 1 interface system
+// redundantly and corrects its row: one round trip.  One wave per (chain, end), four of them per workgroup.
+__global__ __launch_bounds__(256) void k_couple_k1(int nchains, int m, const ChainDesc *chains, const double *tipT, const double *tipB,
+                                                   const double *WT, const double *ST, const double *VT, const double *Wf,
+                                                   const double *Vf, double *y)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per (chain, end)
+    const int p = q >> 1, end = q & 1;                   // end 0: top window (interface p-1 | p), 1: bottom window (p | p+1)
+    if (p >= nchains) return;
+    const int i = end == 0 ? p - 1 : p;                  // interface between chains i and i+1
+    if (i < 0 || i + 1 >= nchains) return;
+    const ChainDesc cd = chains[p];
+    const double gb = tipB[i], gt = tipT[i + 1], w = WT[i], sinv = ST[i], v = VT[i];
+    const double xt = sinv * (gt - w * gb);              // x_t = S^-1 (g_t - W g_b)
+    const double tip = end == 0 ? gb - v * xt : xt;      // the top window takes x_b of the interface above, the bottom one x_t below
+    const double *S = (end == 0 ? Wf : Vf) + (int64_t)p * m;
+    const int64_t row0 = end == 0 ? cd.row0 : cd.row0 + cd.nrows - m;
+    for (int r = lane; r < m; r += 64) y[row0 + r] -= S[r] * tip;
+}
+
 hipError_t launch_couple_small(int nchains, int K, int m, const ChainDesc *chains, double *tips, const double *WT, const double *ST,
                                const double *VT, const double *Wf, const double *Vf, double *y, hipStream_t st, bool tips_ready)
 {
     if (nchains <= 0 || K < 1 || K > 8) return hipErrorInvalidValue;
     double *tipT = tips, *tipB = tips + (size_t)nchains * K;
     if (!tips_ready) hipLaunchKernelGGL(k_tips_small, dim3((nchains * K + 255) / 256), dim3(256), 0, st, nchains, K, chains, y, tipT, tipB);
-    hipLaunchKernelGGL(k_couple_small, dim3(nchains), dim3(64), 0, st, nchains, K, m, chains, tipT, tipB, WT, ST, VT, Wf, Vf, y);
+    if (K == 1) hipLaunchKernelGGL(k_couple_k1, dim3((2 * nchains + 3) / 4), dim3(256), 0, st, nchains, m, chains, tipT, tipB, WT, ST, VT, Wf, Vf, y);
+    else hipLaunchKernelGGL(k_couple_small, dim3(nchains), dim3(64), 0, st, nchains, K, m, chains, tipT, tipB, WT, ST, VT, Wf, Vf, y);
     return hipGetLastError();
 }
 

@@ -77,6 +77,11 @@ typedef struct {
     int32_t spike_rows;      /* rows kept of every spike (0: none, the coupled variant re-solves) */
     int64_t spike_bytes;     /* bytes of stored spikes read per coupled apply */
     int32_t chains_local;    /* chains the kernels sweep: P_local, or a multiple of it when "subsplit" cut the partitions */
+    int32_t twisted;         /* 1: the chains are paired into diagonal blocks factored from both ends (exact seam system per pair,
+                                truncated interfaces with stored spikes only between pairs); P_local then counts the blocks' owners,
+                                i.e. the caller's partitions, or chains_local / 2 when the library chose them */
+    int32_t spike_rows_fp64; /* of spike_rows, the rows next to the interface kept in fp64 (the others in fp32) */
+    int32_t seams_local;     /* seam systems solved between the two sweep launches (= chains_local / 2 when twisted) */
 } spike_info;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -85,7 +90,7 @@ int spike_destroy(spike_handle h);
 int spike_reset(spike_handle h); /* drop the factors, keep options and communicator */
 const char *spike_last_error(spike_handle h);
 
-/* keys: "partitions" (int >=1, or 0 = auto), "variant" ("decoupled"|"coupled"|0|1),
+/* keys (round 3 additions at the end): "partitions" (int >=1, or 0 = auto), "variant" ("decoupled"|"coupled"|0|1),
  *       "boost" (double, relative to max|diag|, default 1e-10), "keep_band" (0|1, default 1),
  *       "spike_storage" ("auto"|"off": keep the spikes' decayed part and apply the coupled variant in ONE pass
  *        when they are short, else/off: second pass over the factors), "spike_tol" (relative drop level, 1e-16),
@@ -98,7 +103,11 @@ const char *spike_last_error(spike_handle h);
  *       "small_coupling_kmax" (0..8, default 1: half-bandwidths up to this take the two-launch narrow-band coupling step
  *        on one rank; same preconditioner),
  *       "gmres_cgs_refinement_type" ("refine_never"|"refine_ifneeded"|"refine_always": the Gram-Schmidt refinement of
- *        spike_gmres, names and default (never) of PETSc's -ksp_gmres_cgs_refinement_type)             */
+ *        spike_gmres, names and default (never) of PETSc's -ksp_gmres_cgs_refinement_type),
+ *       "twist" ("auto"|"off": two-ended factorisation of chain pairs where stored spikes apply; same preconditioner),
+ *       "spike_tol" default 1e-13 since round 3, "spike_fp32" ("auto"|"off": far part of the stored spikes in fp32),
+ *       "iface_form" ("matrix"|"staged": one-stage or three-stage interface solves; same result to rounding),
+ *       "correct_threads" (64|128|256: workgroup size of the spike correction, measurement option)      */
 int spike_set_option(spike_handle h, const char *key, const char *value);
 /* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */
 int spike_set_stream(spike_handle h, void *hip_stream);

@@ -46,7 +46,7 @@ class SpikeInfo(C.Structure):
         ("waves_per_chain", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("nboost", i64),
         ("factor_bytes", i64), ("iface_bytes", i64), ("setup_ms", C.c_double), ("k_extracted", C.c_int32),
         ("frac_extracted", C.c_double), ("passes", C.c_int32), ("spike_rows", C.c_int32), ("spike_bytes", i64),
-        ("chains_local", C.c_int32),
+        ("chains_local", C.c_int32), ("twisted", C.c_int32), ("spike_rows_fp64", C.c_int32), ("seams_local", C.c_int32),
     ]
 
 

@@ -2107,6 +2107,7 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
     o->passes = ((h->variant == SPIKE_VARIANT_COUPLED ? h->nif : h->nif_int) > 0 && h->spike_m == 0) ? 2 : 1;
     o->spike_rows = h->spike_m;
     o->spike_bytes = (int64_t)(h->twisted ? 1 : 2) * ((int64_t)h->spike_m1 * 8 + (int64_t)(h->spike_m - h->spike_m1) * 4) * (int64_t)h->K * h->P;
+    o->twisted = h->twisted ? 1 : 0; o->spike_rows_fp64 = h->spike_m1; o->seams_local = h->nseam;
     o->setup_ms = h->setup_ms; o->k_extracted = h->k_extracted; o->frac_extracted = h->frac_extracted;
     return SPIKE_OK;
 }

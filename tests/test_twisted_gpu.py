@@ -45,11 +45,12 @@ def test_twisted_equals_oracle_and_untwisted(spike, oracle, N, K, P):
         tw = _mk(spike, P, vname, "auto").setup_band(band)
         assert "(twisted pairs)" in tw.view(), tw.view()          # the case really exercises the twisted path
         i = tw.info()
+        assert i.twisted == 1 and i.seams_local * 2 == i.chains_local and 0 < i.spike_rows_fp64 <= i.spike_rows
         assert i.P_local == P and i.passes == 1 and i.chains_local % (2 * P) == 0 and i.nboost == ref.nboost
         xt = tw.apply(f)
         assert _rel(xt, xo) <= TOL, (vname, _rel(xt, xo))
         off = _mk(spike, P, vname, "off").setup_band(band)
-        assert "(twisted pairs)" not in off.view()
+        assert "(twisted pairs)" not in off.view() and off.info().twisted == 0 and off.info().seams_local == 0
         xu = off.apply(f)
         assert _rel(xu, xo) <= TOL
         assert _rel(xt, xu) <= TOL

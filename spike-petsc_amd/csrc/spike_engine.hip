@@ -196,6 +196,8 @@ struct spike_handle_s {
     double *dAt = nullptr;                                // tile-major copy of the band for the Krylov mat-vec (built on first use)
     double *dTips1 = nullptr;                             // K <= 8: saved chain-end values of the swept vector (2 P K doubles)
     int nif_local_all = 0;                                // interfaces between this rank's chains
+    int scan_kmax = DEFAULT_SCAN_KMAX, scan_rows = DEFAULT_SCAN_ROWS;   // wavefront scan for K <= scan_kmax (options narrow_scan_kmax / narrow_scan_rows)
+    int64_t scan_lds = 0;                                 // row stride of the k_nscan_* coefficient arrays
     int small_kmax = 1;                                   // k_couple_small for K <= this (measured: pays at K = 1 only; option small_coupling_kmax)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
@@ -453,6 +455,8 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
         else return fail(h, SPIKE_ERR_ARG, "iface_form is 'matrix' or 'staged'");
     }
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "narrow_scan_kmax") { h->scan_kmax = atoi(val); if (h->scan_kmax < 1 || h->scan_kmax > 3) return fail(h, SPIKE_ERR_ARG, "narrow_scan_kmax must be in 1..3"); }
+    else if (k == "narrow_scan_rows") { h->scan_rows = atoi(val); if (h->scan_rows != 1 && h->scan_rows != 4) return fail(h, SPIKE_ERR_ARG, "narrow_scan_rows is 1 or 4"); }
     else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
     else if (k == "gmres_cgs_refinement_type") {  // PETSc's -ksp_gmres_cgs_refinement_type, same names, same default
         if (v == "refine_never" || v == "never") h->cgs_refine = 0;
@@ -586,6 +590,19 @@ static int auto_partitions(const SweepCfg &cfg, int K, int64_t n, int ncu_dev = 
     // chains of the four-waves rule, and every chain twice as long against the same spike windows.
     if (cfg.NW == 1 && cfg.CPW() > 1) target = ncu * (cfg.R == 32 ? 1 : 2) * cfg.CPW();
     if (cfg.scan) target = 8192;  // one light wave per chain: 32 waves per CU keep enough loads in flight
+    if (cfg.nscan && getenv("SPIKE_AUTO_CHAINS") == nullptr) {
+        // Four rows per lane, forward result in registers: the LONGEST chains the one-launch kernel takes (4096 rows; K = 3:
+        // 2048 -- its 16-block instantiation is slower per row), but at least 8 one-wave chains per CU while that leaves a
+        // chain 512 rows.  Measured (ms per apply; tools/r3_nscan2.sh, profiles/r3_nscan_chains.log), chains 1024/2048/4096/8192:
+        //   K = 1: N = 1M .0128/.0118/.0134/.0198   4M .0391/.0351/.0347/.0365   16M .193*/.193*/.1207/.1339   (* two launches)
+        //   K = 2: N = 1M .0237/.0240/.0323/.0512   4M .0554/.0546/.0667/.0713   16M .257*/.250*/.1798/.1891
+        //   K = 3: N = 1M .0280/.0295/.0378/.0725   4M .0808/.0717/.0847/.0949   16M .334*/.314*/.2867/.2687
+        const int64_t maxblk = (K == 3 ? 2048 : 4096) / BLK;
+        int64_t P = (nblk + maxblk - 1) / maxblk;
+        const int64_t fill = 8 * ncu;
+        if (P < fill) P = std::max<int64_t>(P, std::min<int64_t>(fill, nblk / 8));
+        return (int)std::max<int64_t>(P, 1);
+    }
     // K = 2..4 (16 chains per wave): the stored spikes of a dominant system still reach ~190 rows, so 512-row chains spend
     // three quarters of their rows in correction windows -- 1024-row chains where that still leaves two waves per CU
     // (N = 8M: K = 2 0.230 -> 0.189 ms, K = 4 0.247 -> 0.195), the wave count first where it does not (N = 4M, K = 4:
@@ -738,6 +755,12 @@ static void pick_sweep_shape(spike_handle h, int ncu)
     if (c.R == 64 && c.NW == 2 && sweep_shape_exists(c, 32, 2, 4)) { c.sDPW = 32; c.sNW = 2; c.sPF = 4; }
 }
 
+// scan chains short enough for the one-launch solve (forward result in registers)
+static bool scan_fused(spike_handle h)
+{
+    return h->cfg.scan && h->max_chain_rows <= (h->cfg.nscan ? nscan_max_rows(h->K) : 64 * 64);
+}
+
 // one forward+backward pass over all chains: out = blockdiag(A_p)^{-1} (in - corrections)
 struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes are computed only where they live)
     const ChainDesc *chains = nullptr;
@@ -768,17 +791,19 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
         else { (void)hipEventRecord(h->evs[h->nev].second, st); ++h->nev; }
     };
     const int tag = h->ready ? 0 : 1;  // setup (spike solves) vs PCApply: distinct kernel names in a trace
-    if (h->cfg.scan && h->max_chain_rows <= 64 * 64) {
-        // tridiagonal chains of at most 4096 rows: both sweeps in one launch, the intermediate vector stays in registers
+    if (scan_fused(h)) {
+        // scan chains of at most 4096 rows: both sweeps in one launch, the intermediate vector stays in registers
         a.out = out;
-        if (h->ready && !with_corr && h->dTips1 != nullptr) { a.tipT = h->dTips1; a.tipB = h->dTips1 + (size_t)h->P; }   // for k_couple_small
+        if (h->ready && !with_corr && h->dTips1 != nullptr) { a.tipT = h->dTips1; a.tipB = h->dTips1 + (size_t)h->P * h->K; }   // for k_couple_small
         rec(true);
-        HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, st, tag));
+        if (h->cfg.nscan) HIPCHK(launch_nscan_solve(h->K, h->P, h->max_chain_rows, a, h->dUt, h->scan_lds, st, tag));
+        else HIPCHK(launch_scan_solve(h->P, h->max_chain_rows, a, h->dUt, st, tag));
         rec(false);
         return SPIKE_OK;
     }
     rec(true);
-    if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, st, tag));
+    if (h->cfg.nscan) HIPCHK(launch_nscan_sweep(h->K, false, h->P, a, h->dLt, h->scan_lds, st, tag));
+    else if (h->cfg.scan) HIPCHK(launch_scan_sweep(false, h->P, a, st, tag));
     else HIPCHK(launch_sweep(h->cfg, false, ng, a, st, tag));
     rec(false);
     // twisted: both halves of every diagonal block have swept inward; their seam systems (2K x 2K, exact) are solved in
@@ -790,7 +815,8 @@ static int run_pass(spike_handle h, const double *in, double *out, bool with_cor
     a.tiles = h->dUt; a.in = h->dY; a.out = out; a.dinv = nullptr; a.corr_top = a.corr_bot = nullptr;
     if (sub) a.groups = sub->groupsB;
     rec(true);
-    if (h->cfg.scan) HIPCHK(launch_scan_sweep(true, h->P, a, st, tag));
+    if (h->cfg.nscan) HIPCHK(launch_nscan_sweep(h->K, true, h->P, a, h->dUt, h->scan_lds, st, tag));
+    else if (h->cfg.scan) HIPCHK(launch_scan_sweep(true, h->P, a, st, tag));
     else HIPCHK(launch_sweep(h->cfg, true, ng, a, st, tag));
     rec(false);
     return SPIKE_OK;
@@ -849,7 +875,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     if (h->nranks == 1 && (row0 != 0 || n != n_global)) return fail(h, SPIKE_ERR_ARG, "single rank must own all rows");
     if (n > 2000000000LL) return fail(h, SPIKE_ERR_ARG, "n_local too large");
     SweepCfg cfg;
-    if (!pick_cfg(K, &cfg)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..512)", K);
+    if (!pick_cfg(K, &cfg, h->scan_kmax, h->scan_rows)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..512)", K);
     (void)hipStreamSynchronize(h->stream);
     free_factors(h);
     TmpPool tmp;
@@ -1002,18 +1028,20 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(launch_factor(dLU, n, K, h->dChainsV, P, boost, dNb, st));
     mark("LU copy + factor");
     // scan path (K = 1): "tiles" are plain per-row arrays, dLt = l, dUt = c
-    const size_t tile_total = cfg.scan ? (size_t)n : (size_t)h->ntiles * (size_t)cfg.tile_doubles();
+    h->scan_lds = (n + 3) & ~(int64_t)3;
+    const size_t tile_total = cfg.nscan ? (size_t)K * (size_t)h->scan_lds : cfg.scan ? (size_t)n : (size_t)h->ntiles * (size_t)cfg.tile_doubles();
     h->factor_doubles = tile_total;
     HIPCHK(dalloc(&h->dLt, tile_total));
     HIPCHK(dalloc(&h->dUt, tile_total));
-    HIPCHK(dalloc(&h->dDinv, (size_t)n));
+    HIPCHK(dalloc(&h->dDinv, (size_t)n + 4));   // (+4: the scan kernels read whole 4-row groups)
     HIPCHK(dalloc(&h->dY, (size_t)n));
     HIPCHK(dalloc(&h->dTmp, (size_t)n));
     if (!(cfg.R == 64 && !cfg.scan && K <= 256)) {   // k_pack64 writes every entry of every tile, zeros included
         HIPCHK(hipMemsetAsync(h->dLt, 0, tile_total * sizeof(double), st));
         HIPCHK(hipMemsetAsync(h->dUt, 0, tile_total * sizeof(double), st));
     }
-    if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChainsV, P, h->dLt, h->dUt, h->dDinv, st));
+    if (cfg.nscan) HIPCHK(launch_pack_nscan(dLU, n, K, h->dChainsV, P, h->dLt, h->dUt, h->scan_lds, h->dDinv, st));
+    else if (cfg.scan) HIPCHK(launch_pack_scan(dLU, n, h->dChainsV, P, h->dLt, h->dUt, h->dDinv, st));
     else HIPCHK(launch_pack(cfg, dLU, n, K, h->dChainsV, h->dGroups, P, h->maxsteps, nullptr, h->dLt, h->dUt, h->dDinv, st));
     unsigned long long nb = 0;
     HIPCHK(hipMemcpyAsync(&nb, dNb, sizeof nb, hipMemcpyDeviceToHost, st));
@@ -1626,7 +1654,7 @@ static int apply_dev(spike_handle h, const double *x, double *y)
     if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
         h->nif_local_all == P - 1 && !h->twisted && h->spike_m1 == h->spike_m)
         return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st,
-                                   /*tips_ready=*/h->cfg.scan && h->max_chain_rows <= 64 * 64) == hipSuccess
+                                   /*tips_ready=*/scan_fused(h)) == hipSuccess
                    ? SPIKE_OK : fail(h, SPIKE_ERR_HIP, "k_couple_small launch failed");
     // main stream first (asynchronous launches): a collective call may hold the host for a moment
     HIPCHK(iface_launch(nloc, ifs, st));

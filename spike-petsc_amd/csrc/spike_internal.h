@@ -41,6 +41,7 @@ struct SweepCfg {
     int DPW;  // diagonals per wave (= tile entries per lane per wave)
     int NW;   // waves per chain
     bool scan = false;  // K = 1: no tiles, one multiplier per row, wavefront scan (k_scan_sweep)
+    bool nscan = false; // scan with four rows per lane (k_nscan_*, K = 1..3): coefficient arrays [K][lds]
     // sweep-time shape of PCApply (0 = the base shape above): the tile layout is independent of how the KP diagonals are
     // dealt to waves, so setup may pick another (DPW, NW, prefetch depth) for the apply sweeps (launch_sweep)
     int sDPW = 0, sNW = 0, sPF = 0;
@@ -82,7 +83,8 @@ struct IfaceDesc {
     double *xt_out;    // K doubles: x^(t), top-tip solution of the lower partition, or null
 };
 
-bool pick_cfg(int K, SweepCfg *cfg);
+constexpr int DEFAULT_SCAN_KMAX = 3, DEFAULT_SCAN_ROWS = 4;   // (handle options narrow_scan_kmax / narrow_scan_rows)
+bool pick_cfg(int K, SweepCfg *cfg, int scan_kmax = DEFAULT_SCAN_KMAX, int scan_rows = DEFAULT_SCAN_ROWS);
 bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf);
 
 // launchers (spike_kernels.hip)
@@ -110,6 +112,12 @@ hipError_t launch_pack_scan(const double *lu, int64_t ld, const ChainDesc *chain
 hipError_t launch_scan_sweep(bool rev, int nchains, const SweepArgs &a, hipStream_t st, int tag = 0);
 // both sweeps in one launch, the intermediate vector in registers (chains of at most 4096 rows); a.tiles = l, cu = c
 hipError_t launch_scan_solve(int nchains, int max_rows, const SweepArgs &a, const double *cu, hipStream_t st, int tag = 0);
+// K = 1..3, four rows per lane (k_nscan_*): coefficient arrays [K][lds] (lds a multiple of 4), see launch_pack_nscan
+int nscan_max_rows(int K);
+hipError_t launch_nscan_solve(int K, int nchains, int max_rows, const SweepArgs &a, const double *cu, int64_t lds, hipStream_t st, int tag = 0);
+hipError_t launch_nscan_sweep(int K, bool rev, int nchains, const SweepArgs &a, const double *coef, int64_t lds, hipStream_t st, int tag = 0);
+hipError_t launch_pack_nscan(const double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double *l, double *c,
+                             int64_t lds, double *dinv, hipStream_t st);
 hipError_t launch_absmax_diag(const double *band, int64_t ld, int K, int64_t n, double *out, hipStream_t st);
 hipError_t launch_gen_band(int64_t N, int K, uint64_t seed, double delta, int64_t row0, int64_t nrows, double *band,
                            int64_t ld, hipStream_t st);

@@ -37,14 +37,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------
 // configuration
 // ------------------------------------------------------------------------------------------
-bool pick_cfg(int K, SweepCfg *cfg)
+bool pick_cfg(int K, SweepCfg *cfg, int scan_kmax, int scan_rows)
 {
     if (K < 0 || K > 512) return false;
+    if (scan_kmax > 3) scan_kmax = 3;
     // 256 < K <= 512 (round 3): supported, not tuned.  64 diagonals per wave, 5..8 waves per chain, one bundle in flight (the
     // bundle alone is 128 VGPRs); setup takes the generic paths (diagonal-major LU scratch, scalar right-looking
     // factorisation, spike columns one at a time through the sweep kernels, no twisting)
     if (K > 256) { *cfg = {64, 64, (K + 63) / 64}; return true; }
-    if (K == 1) { *cfg = {64, 2, 1}; cfg->scan = true; }  // tridiagonal: wavefront scan, 56 bytes per row and pass
+    // K <= scan_kmax: wavefront scan (no tiles); nscan = the four-rows-per-lane kernels (k_nscan_*: always for K = 2, 3)
+    if (K >= 1 && K <= scan_kmax) { *cfg = {64, 2, 1}; cfg->scan = true; cfg->nscan = K > 1 || scan_rows == 4; }
     // 16 chains per wave; tridiagonal and pentadiagonal systems stream 4 diagonals, not 8.  (Round 3 measured a 2-row /
     // 2-diagonal configuration for K = 2 -- tiles that hold exactly the band, 9 instead of 13 doubles per row and pass, 32
     // chains per wave: 0.216-0.220 ms per apply at N = 8M against 0.179 for this one, gpurun_out/r3/k2_ab.log: twice the block
@@ -714,6 +716,506 @@ hipError_t launch_pack_scan(const double *lu, int64_t ld, const ChainDesc *chain
 {
     if (nchains <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_pack_scan, dim3(8, nchains), dim3(256), 0, st, lu, ld, chains, l, c, dinv);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_nscan_*: the wavefront scan for K = 1..3 with FOUR ROWS PER LANE (round 3).
+//
+// A banded recurrence  v_i = r_i - sum_{d=1..K} a_{i,d} v_{i-d}  carries the state s_i = (v_i, ..., v_{i-K+1}); a run of
+// rows is an affine map of that state (K x K matrix + K vector).  A lane owns 4 consecutive rows: it forms their map by
+// running the recurrence 1 + K times over its own rows (right-hand side, and one unit state component each) -- serial, but
+// in registers and without any cross-lane traffic; ONE 64-lane scan of those maps (6 DPP steps) then resolves 256 rows.
+// Against one row per lane (k_scan_solve, K = 1) the cross-lane work per row drops 4x; for K = 2 the scan step moves 6
+// doubles and costs 12 multiply-adds, which at one row per lane is ~6x the work of the tridiagonal scan (why round 2 did
+// not build it) and at four rows per lane about the same as that kernel's.  The lane's 4 rows are 32 contiguous bytes of
+// every array: two 16-byte loads per array, 2 KiB contiguous per wave.
+// The forward result stays in registers (4 * MAXIT doubles per lane), the backward recurrence runs on mirrored lanes and
+// takes it from there: l_1..l_K, 1/u, rhs in, c_1..c_K, x out = (2K + 3) * 8 bytes per row, the algorithmic traffic of a
+// banded solve.  Chains longer than 256 * MAXIT rows: k_nscan_sweep (two launches, intermediate vector in HBM).
+// Coefficient arrays: diagonal-major, row stride lds (a multiple of 4 doubles), zero where the neighbour lies outside
+// the chain, so a chain needs no special first / last rows.
+// ------------------------------------------------------------------------------------------
+constexpr int NSCAN_RPL = 4;
+constexpr int NSCAN_BLK = 64 * NSCAN_RPL;
+
+template <int KK>
+struct ScanMap {
+    double A[KK][KK];
+    double c[KK];
+};
+
+template <int KK, int CTRL, int ROWMASK>
+__device__ __forceinline__ void scanmap_step(ScanMap<KK> &m)
+{
+    ScanMap<KK> u, r;   // u: the map of the lanes before (identity where DPP has no source lane)
+#pragma unroll
+    for (int f = 0; f < KK; ++f) {
+#pragma unroll
+        for (int e = 0; e < KK; ++e) u.A[f][e] = dpp_move<CTRL, ROWMASK>(f == e ? 1.0 : 0.0, m.A[f][e]);
+        u.c[f] = dpp_move<CTRL, ROWMASK>(0.0, m.c[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < KK; ++f) {
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+            double s = m.A[f][0] * u.A[0][e];
+#pragma unroll
+            for (int g = 1; g < KK; ++g) s = fma(m.A[f][g], u.A[g][e], s);
+            r.A[f][e] = s;
+        }
+        double s = m.c[f];
+#pragma unroll
+        for (int g = 0; g < KK; ++g) s = fma(m.A[f][g], u.c[g], s);
+        r.c[f] = s;
+    }
+    m = r;
+}
+
+template <int KK>
+__device__ __forceinline__ void scanmap_scan64(ScanMap<KK> &m)
+{
+    scanmap_step<KK, 0x111, 0xF>(m);  // row_shr:1
+    scanmap_step<KK, 0x112, 0xF>(m);  // row_shr:2
+    scanmap_step<KK, 0x114, 0xF>(m);  // row_shr:4
+    scanmap_step<KK, 0x118, 0xF>(m);  // row_shr:8
+    scanmap_step<KK, 0x142, 0xA>(m);  // row_bcast:15 into rows 1 and 3
+    scanmap_step<KK, 0x143, 0xC>(m);  // row_bcast:31 into rows 2 and 3
+}
+
+// Operand access: BUFFER loads / stores through a per-(array, block) descriptor whose range is the rows of the block that
+// belong to the chain -- the hardware returns zeros beyond it (= "no neighbour": exactly what a row past the chain end must
+// contribute) and drops stores, so the kernels have NO per-lane branches around memory operations.  (First version: a
+// per-lane `if (4 rows valid) 16-byte loads else guarded 8-byte loads` -- the compiler merged the two paths' registers with
+// copies right behind every load, i.e. waited for each load on the spot: 147 x s_waitcnt vmcnt(0) in the K = 2 kernel, one
+// load in flight per wave however far ahead the source asked for the next block.)
+// WIDE (vectors 32-byte aligned; the library's own arrays always): two 16-byte accesses per lane; the range is rounded up
+// to whole 4-row groups, so no access straddles its end (a ragged chain end -- only the last chain of a rank, n not a
+// multiple of 4 -- is masked after the load and stored element-wise).  Otherwise four 8-byte accesses, exact range.
+typedef unsigned int nscan_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nscan_u2 __attribute__((ext_vector_type(2)));
+constexpr int NSCAN_AUX_NT = 2;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nscan_rsrc(const double *base, int rows, bool round4)
+{
+    int r = rows < 0 ? 0 : (rows > NSCAN_BLK ? NSCAN_BLK : rows);
+    if (round4) r = (r + 3) & ~3;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, r * 8, 0x00020000);
+}
+
+template <bool WIDE, int AUX>
+__device__ __forceinline__ void nscan_bload4(__amdgpu_buffer_rsrc_t r, int voff, double (&v)[4])
+{
+    if (WIDE) {
+        const d2 a = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, AUX));
+        const d2 b = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, 0, AUX));
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + 8 * j, 0, AUX));
+    }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void nscan_bstore4(__amdgpu_buffer_rsrc_t r, int voff, const double (&v)[4])
+{
+    if (WIDE) {
+        d2 a, b;
+        a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nscan_u4, a), r, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nscan_u4, b), r, voff + 16, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(nscan_u2, v[j]), r, voff + 8 * j, 0, 0);
+    }
+}
+
+// One block of 256 positions in sweep order: lane owns positions 4 lane .. 4 lane + 3 with coefficients a[d][j] (of
+// v_{j-1-d}) and right-hand sides r[j].  S = state entering the block (wave-uniform: S[e] = v at position -1-e), replaced
+// by the state leaving it.  Everything up to the scan is independent of S.
+template <int KK>
+struct NScanBlock {
+    double h[KK][4], p[4];
+    ScanMap<KK> m;
+    __device__ __forceinline__ void prepare(const double (&a)[KK][4], const double (&r)[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double pj = r[j];
+#pragma unroll
+            for (int d = 0; d < KK; ++d)
+                if (j - 1 - d >= 0) pj = fma(-a[d][j], p[j - 1 - d], pj);
+            p[j] = pj;
+#pragma unroll
+            for (int e = 0; e < KK; ++e) {
+                double hj = 0.0;
+#pragma unroll
+                for (int d = 0; d < KK; ++d) {
+                    const int idx = j - 1 - d;
+                    if (idx >= 0) hj = fma(-a[d][j], h[e][idx], hj);
+                    else if (-1 - idx == e) hj -= a[d][j];
+                }
+                h[e][j] = hj;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < KK; ++f) {
+#pragma unroll
+            for (int e = 0; e < KK; ++e) m.A[f][e] = h[e][3 - f];
+            m.c[f] = p[3 - f];
+        }
+        scanmap_scan64<KK>(m);
+    }
+    __device__ __forceinline__ void finish(double (&S)[KK], double (&v)[4])
+    {
+        double out[KK], in[KK];
+#pragma unroll
+        for (int f = 0; f < KK; ++f) {
+            double s = m.c[f];
+#pragma unroll
+            for (int e = 0; e < KK; ++e) s = fma(m.A[f][e], S[e], s);
+            out[f] = s;
+        }
+#pragma unroll
+        for (int f = 0; f < KK; ++f) in[f] = dpp_move<0x138, 0xF>(S[f], out[f]);   // wave_shr:1, lane 0 keeps S
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = p[j];
+#pragma unroll
+            for (int e = 0; e < KK; ++e) s = fma(h[e][j], in[e], s);
+            v[j] = s;
+        }
+#pragma unroll
+        for (int f = 0; f < KK; ++f) S[f] = last_lane(out[f]);
+    }
+};
+
+struct NScanArgs {
+    const double *lco, *uco, *dinv;   // [K][lds] multipliers, [K][lds] U / diag, [n] 1 / diag
+    int64_t lds;
+    const ChainDesc *chains;
+    int nchains;
+    const double *in;
+    double *out;
+    const double *corr_top, *corr_bot;
+    double *tipT, *tipB;
+};
+
+// raw operands of one block: forward = multipliers + right-hand side, backward = U / diag + 1 / diag (the forward result is
+// scaled by 1 / diag on its way INTO the backward recurrence: both directions then load K + 1 arrays per row)
+template <int KK>
+struct NScanRaw {
+    double a[KK][4], r[4];
+};
+
+// wave-uniform view of a chain (the chain index comes from threadIdx: make uniformity provable for the descriptors)
+struct NScanChain {
+    int64_t row0;
+    int nrows, p;
+};
+
+__device__ __forceinline__ bool nscan_chain(const NScanArgs &s, NScanChain &c)
+{
+    c.p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (c.p >= s.nchains) return false;
+    const ChainDesc cd = s.chains[c.p];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(cd.row0 & 0xffffffffll));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)cd.row0 >> 32));
+    c.row0 = (int64_t)(((uint64_t)hi << 32) | lo);
+    c.nrows = __builtin_amdgcn_readfirstlane(cd.nrows);
+    return true;
+}
+
+// The load functions ONLY issue loads (into the ring slot, rows in memory order); everything that reads the loaded values --
+// ragged-end masks, boundary corrections, the reversal for the backward direction -- happens in the *_use functions right
+// before the block is processed, so that nothing waits for a load before its block's turn.
+template <int KK, bool AL>
+__device__ __forceinline__ void nscan_load_fwd(NScanRaw<KK> &q, const NScanArgs &s, const NScanChain &c, int it, int lane)
+{
+    const int left = c.nrows - it * NSCAN_BLK;
+    const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
+    const int voff = 32 * lane;
+#pragma unroll
+    for (int d = 0; d < KK; ++d) nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.lco + d * s.lds + g, left, true), voff, q.a[d]);
+    nscan_bload4<AL, 0>(nscan_rsrc(s.in + g, left, AL), voff, q.r);
+}
+
+template <int KK>
+__device__ __forceinline__ void nscan_use_fwd(NScanRaw<KK> &q, const NScanArgs &s, const NScanChain &c, int it, int lane)
+{
+    const int left = c.nrows - it * NSCAN_BLK;
+    if (left < NSCAN_BLK && (left & 3)) {   // ragged end (wave-uniform test): the last 4-row group reaches past the chain
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = 4 * lane + j < left;
+#pragma unroll
+            for (int d = 0; d < KK; ++d) q.a[d][j] = ok ? q.a[d][j] : 0.0;
+            q.r[j] = ok ? q.r[j] : 0.0;
+        }
+    }
+    if (s.corr_top != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = it * NSCAN_BLK + 4 * lane + j;
+            if (r < KK && r < c.nrows) q.r[j] -= s.corr_top[(int64_t)c.p * KK + r];
+            if (r >= c.nrows - KK && r < c.nrows) q.r[j] -= s.corr_bot[(int64_t)c.p * KK + (r - (c.nrows - KK))];
+        }
+    }
+}
+
+// backward: position q of block `it` = local row 256 it + 255 - q; the lane's 4 rows start at 4 (63 - lane) and are taken in
+// reverse.  q.r receives 1 / diag of those rows (0 past the chain end: the forward value there is 0 as well).
+template <int KK>
+__device__ __forceinline__ void nscan_load_bwd(NScanRaw<KK> &q, const NScanArgs &s, const NScanChain &c, int it, int lane)
+{
+    const int left = c.nrows - it * NSCAN_BLK;
+    const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
+    const int voff = 32 * (63 - lane);
+#pragma unroll
+    for (int d = 0; d < KK; ++d) nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.uco + d * s.lds + g, left, true), voff, q.a[d]);
+    nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.dinv + g, left, true), voff, q.r);
+}
+
+template <int KK>
+__device__ __forceinline__ void nscan_use_bwd(const NScanRaw<KK> &q, const NScanChain &c, int it, int lane, double (&a)[KK][4], double (&dv)[4])
+{
+    const int left = c.nrows - it * NSCAN_BLK;
+    const bool ragged = left < NSCAN_BLK && (left & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = !ragged || 4 * (63 - lane) + 3 - j < left;
+#pragma unroll
+        for (int d = 0; d < KK; ++d) a[d][j] = ok ? q.a[d][3 - j] : 0.0;
+        dv[j] = ok ? q.r[3 - j] : 0.0;
+    }
+}
+
+template <int KK, bool AL>
+__device__ __forceinline__ void nscan_store_bwd(const double (&v)[4], const NScanArgs &s, const NScanChain &c, int it, int lane)
+{
+    const int left = c.nrows - it * NSCAN_BLK;
+    const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
+    const int voff = 32 * (63 - lane);
+    double x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = v[3 - k];
+    const __amdgpu_buffer_rsrc_t ro = nscan_rsrc(s.out + g, left, false);   // exact range: nothing is written past the chain
+    if (AL && !(left < NSCAN_BLK && (left & 3))) nscan_bstore4<true>(ro, voff, x);
+    else nscan_bstore4<false>(ro, voff, x);
+    if (s.tipT != nullptr) {   // the coupling step wants the chain-end values BEFORE the corrections touch them
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = it * NSCAN_BLK + 4 * (63 - lane) + k;
+            if (r < KK && r < c.nrows) s.tipT[(int64_t)c.p * KK + r] = x[k];
+            if (r >= c.nrows - KK && r < c.nrows) s.tipB[(int64_t)c.p * KK + (r - (c.nrows - KK))] = x[k];
+        }
+    }
+}
+
+// NS = blocks in flight per wave and direction: a block's operands are requested NS blocks ahead, into the ring slot the
+// block NS before it has just been read out of (slot = block index mod NS: compile-time in the unrolled loops).  A block
+// is ~800 cycles of work against ~2 us of loaded memory latency and only two or three waves fit a SIMD (the forward
+// result alone is 8 * MAXIT registers).
+// Every load of the schedule is issued UNCONDITIONALLY -- a block past the chain's last one gets a zero-length descriptor
+// and costs an instruction, no traffic.  With a load under `if (block < nblk)` the compiler's wait-count bookkeeping
+// has to assume at each join that the load may not have been issued, i.e. that fewer loads are in flight than really
+// are, and the wait for block i's operands (loads return in order) degenerates to "wait for everything": the prefetch
+// was in the source and not in the machine code (vmcnt(0) before every block).
+template <int KK, int MAXIT, bool AL, int TAG, int NS>
+__global__ __launch_bounds__(256) void k_nscan_solve(NScanArgs s)
+{
+    const int lane = threadIdx.x & 63;
+    NScanChain c;
+    if (!nscan_chain(s, c)) return;
+    const int nblk = (c.nrows + NSCAN_BLK - 1) / NSCAN_BLK;   // host guarantees nblk <= MAXIT
+    double z[MAXIT][4];
+    double S[KK];
+#pragma unroll
+    for (int e = 0; e < KK; ++e) S[e] = 0.0;
+    NScanRaw<KK> q[NS];
+#pragma unroll
+    for (int it = -NS; it < MAXIT; ++it) {
+        if (it >= 0) {
+            if (it < nblk) {
+                NScanBlock<KK> b;
+                nscan_use_fwd<KK>(q[it % NS], s, c, it, lane);
+                b.prepare(q[it % NS].a, q[it % NS].r);
+                b.finish(S, z[it]);
+            }
+        }
+        if (it + NS < MAXIT) nscan_load_fwd<KK, AL>(q[(it + NS) % NS], s, c, it + NS, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < KK; ++e) S[e] = 0.0;
+#pragma unroll
+    for (int it = MAXIT - 1 + NS; it >= 0; --it) {
+        if (it < MAXIT) {
+            if (it < nblk) {
+                double a[KK][4], r[4];
+                nscan_use_bwd<KK>(q[it % NS], c, it, lane, a, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] *= __shfl(z[it][3 - j], 63 - lane);   // the mirrored lane's row, / diag
+                NScanBlock<KK> b;
+                b.prepare(a, r);
+                double v[4];
+                b.finish(S, v);
+                nscan_store_bwd<KK, AL>(v, s, c, it, lane);
+            }
+        }
+        if (it - NS >= 0) nscan_load_bwd<KK>(q[it % NS], s, c, it - NS, lane);
+    }
+}
+
+// one direction per launch, any chain length: forward writes D^{-1} L^{-1} r to `out`, backward solves with the unit upper
+// factor (in = the forward result)
+template <int KK, bool REV, bool AL, int TAG>
+__global__ __launch_bounds__(256) void k_nscan_sweep(NScanArgs s)
+{
+    const int lane = threadIdx.x & 63;
+    NScanChain c;
+    if (!nscan_chain(s, c)) return;
+    const int nblk = (c.nrows + NSCAN_BLK - 1) / NSCAN_BLK;
+    double S[KK];
+#pragma unroll
+    for (int e = 0; e < KK; ++e) S[e] = 0.0;
+    if (!REV) {
+        NScanRaw<KK> cur, nxt;
+        double dvc[4], dvn[4];
+        auto load = [&](NScanRaw<KK> &q, double (&dv)[4], int it) {
+            nscan_load_fwd<KK, AL>(q, s, c, it, lane);
+            nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.dinv + c.row0 + (int64_t)it * NSCAN_BLK, c.nrows - it * NSCAN_BLK, true), 32 * lane, dv);
+        };
+        load(cur, dvc, 0);
+        for (int it = 0; it < nblk; ++it) {
+            if (it + 1 < nblk) load(nxt, dvn, it + 1);
+            NScanBlock<KK> b;
+            nscan_use_fwd<KK>(cur, s, c, it, lane);
+            b.prepare(cur.a, cur.r);
+            double v[4];
+            b.finish(S, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= dvc[j];
+            const int left = c.nrows - it * NSCAN_BLK;
+            const __amdgpu_buffer_rsrc_t ro = nscan_rsrc(s.out + c.row0 + (int64_t)it * NSCAN_BLK, left, false);
+            if (AL && !(left < NSCAN_BLK && (left & 3))) nscan_bstore4<true>(ro, 32 * lane, v);
+            else nscan_bstore4<false>(ro, 32 * lane, v);
+            if (it + 1 < nblk) {
+                cur = nxt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dvc[j] = dvn[j];
+            }
+        }
+    } else {
+        for (int it = nblk - 1; it >= 0; --it) {
+            NScanRaw<KK> q;
+            double t[4], r[4], a[KK][4], dv[4];
+            nscan_load_bwd<KK>(q, s, c, it, lane);   // (1 / diag: not needed here, the forward launch has applied it)
+            const int left = c.nrows - it * NSCAN_BLK;
+            nscan_bload4<AL, 0>(nscan_rsrc(s.in + c.row0 + (int64_t)it * NSCAN_BLK, left, AL), 32 * (63 - lane), t);
+            nscan_use_bwd<KK>(q, c, it, lane, a, dv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (4 * (63 - lane) + 3 - j < left) ? t[3 - j] : 0.0;
+            NScanBlock<KK> b;
+            b.prepare(a, r);
+            double v[4];
+            b.finish(S, v);
+            nscan_store_bwd<KK, AL>(v, s, c, it, lane);
+        }
+    }
+}
+
+template <int KK, bool AL, int TAG>
+static hipError_t launch_nscan_solve_t(int nchains, int max_rows, const NScanArgs &a, hipStream_t st)
+{
+    // NS = 2: measured equal to 3 and 4 blocks in flight (profiles/r3_nscan_depth.log, taken with a since-removed launch knob: K = 2, N = 8M: 0.0965 / 0.0976 / 0.0992 ms per
+    // apply; K = 1, N = 16M: 0.1202 / 0.1207 / 0.1197) -- the kernel runs at 93 % of the box's measured read ceiling, the
+    // registers are better spent on nothing
+    constexpr int NS = 2;
+    const dim3 g((nchains + 3) / 4), b(256);
+    if (max_rows <= 4 * NSCAN_BLK) hipLaunchKernelGGL((k_nscan_solve<KK, 4, AL, TAG, NS>), g, b, 0, st, a);
+    else if (max_rows <= 8 * NSCAN_BLK) hipLaunchKernelGGL((k_nscan_solve<KK, 8, AL, TAG, NS>), g, b, 0, st, a);
+    else if (KK < 3 && max_rows <= 16 * NSCAN_BLK) hipLaunchKernelGGL((k_nscan_solve<KK, (KK < 3 ? 16 : 8), AL, TAG, NS>), g, b, 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+static NScanArgs nscan_args(const SweepArgs &a, const double *cu, int64_t lds)
+{
+    NScanArgs s;
+    s.lco = a.tiles; s.uco = cu; s.dinv = a.dinv; s.lds = lds; s.chains = a.chains; s.nchains = a.nchains;
+    s.in = a.in; s.out = a.out; s.corr_top = a.corr_top; s.corr_bot = a.corr_bot; s.tipT = a.tipT; s.tipB = a.tipB;
+    return s;
+}
+
+// K = 3: 64 registers of forward result + three blocks of operands + the 3 x 3 maps do not fit; its 16-block instantiation
+// kept the result in scratch memory (measured slower than 2048-row chains)
+int nscan_max_rows(int K) { return (K < 3 ? 16 : 8) * NSCAN_BLK; }
+
+// forward + backward in one launch (chains of at most nscan_max_rows() rows); a.tiles = multipliers, cu = U / diag
+hipError_t launch_nscan_solve(int K, int nchains, int max_rows, const SweepArgs &a, const double *cu, int64_t lds, hipStream_t st, int tag)
+{
+    if (nchains <= 0) return hipSuccess;
+    if (K < 1 || K > 3 || (lds & 3)) return hipErrorInvalidValue;
+    const NScanArgs s = nscan_args(a, cu, lds);
+    const bool al = (((uintptr_t)a.in | (uintptr_t)a.out) & 31) == 0;
+#define NSCAN_GO(KK)                                                                                   \
+    (al ? (tag == 0 ? launch_nscan_solve_t<KK, true, 0>(nchains, max_rows, s, st)                      \
+                    : launch_nscan_solve_t<KK, true, 1>(nchains, max_rows, s, st))                     \
+        : launch_nscan_solve_t<KK, false, 0>(nchains, max_rows, s, st))
+    switch (K) {
+    case 1: return NSCAN_GO(1);
+    case 2: return NSCAN_GO(2);
+    default: return NSCAN_GO(3);
+    }
+#undef NSCAN_GO
+}
+
+hipError_t launch_nscan_sweep(int K, bool rev, int nchains, const SweepArgs &a, const double *coef, int64_t lds, hipStream_t st, int tag)
+{
+    if (nchains <= 0) return hipSuccess;
+    if (K < 1 || K > 3 || (lds & 3)) return hipErrorInvalidValue;
+    NScanArgs s = nscan_args(a, coef, lds);
+    s.lco = coef;
+    const bool al = (((uintptr_t)a.in | (uintptr_t)a.out) & 31) == 0;
+    const dim3 g((nchains + 3) / 4), b(256);
+    (void)tag;
+#define NSCAN_SW(KK)                                                                                   \
+    do {                                                                                               \
+        if (rev) { if (al) hipLaunchKernelGGL((k_nscan_sweep<KK, true, true, 0>), g, b, 0, st, s);     \
+                   else hipLaunchKernelGGL((k_nscan_sweep<KK, true, false, 0>), g, b, 0, st, s); }     \
+        else { if (al) hipLaunchKernelGGL((k_nscan_sweep<KK, false, true, 0>), g, b, 0, st, s);        \
+               else hipLaunchKernelGGL((k_nscan_sweep<KK, false, false, 0>), g, b, 0, st, s); }        \
+    } while (0)
+    switch (K) {
+    case 1: NSCAN_SW(1); break;
+    case 2: NSCAN_SW(2); break;
+    default: NSCAN_SW(3); break;
+    }
+#undef NSCAN_SW
+    return hipGetLastError();
+}
+
+// LU band (diagonal-major) -> the scan's coefficient arrays
+__global__ void k_pack_nscan(const double *lu, int64_t ld, int K, const ChainDesc *chains, double *l, double *c, int64_t lds,
+                             double *dinv)
+{
+    const ChainDesc cd = chains[blockIdx.y];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cd.nrows; r += gridDim.x * blockDim.x) {
+        const int64_t i = cd.row0 + r;
+        const double di = 1.0 / lu[(int64_t)K * ld + i];
+        dinv[i] = di;
+        for (int d = 1; d <= K; ++d) {
+            l[(int64_t)(d - 1) * lds + i] = (r - d >= 0) ? lu[(int64_t)(K - d) * ld + i] : 0.0;
+            c[(int64_t)(d - 1) * lds + i] = (r + d < cd.nrows) ? lu[(int64_t)(K + d) * ld + i] * di : 0.0;
+        }
+    }
+}
+
+hipError_t launch_pack_nscan(const double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double *l, double *c,
+                             int64_t lds, double *dinv, hipStream_t st)
+{
+    if (nchains <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_nscan, dim3(8, nchains), dim3(256), 0, st, lu, ld, K, chains, l, c, lds, dinv);
     return hipGetLastError();
 }
 

@@ -69,7 +69,13 @@ def test_auto_partition_rule_is_cu_balanced(spike):
     assert L.spike_auto_partitions(32, N) == 512           # 2 chains per wave: one workgroup per CU (measured: fewer, longer chains win for K <= 32)
     assert L.spike_auto_partitions(8, 2 * N) == 4096       # 8 chains per wave, two waves per CU
     assert L.spike_auto_partitions(4, 2 * N) == 8192       # 16 chains per wave, two waves per CU, >= 1024 rows per chain
-    assert L.spike_auto_partitions(1, 2 ** 24) == 8192     # scan path
+    # wavefront scan, four rows per lane (K <= 3): the longest chains the one-launch kernel takes (4096 rows; K = 3: 2048),
+    # at least 8 one-wave chains per CU while that leaves 512 rows per chain
+    assert L.spike_auto_partitions(1, 2 ** 24) == 4096
+    assert L.spike_auto_partitions(2, 2 ** 23) == 2048
+    assert L.spike_auto_partitions(3, 2 ** 23) == 4096
+    assert L.spike_auto_partitions(2, 2 ** 20) == 2048
+    assert L.spike_auto_partitions(2, 16384) == 32
     assert L.spike_auto_partitions(128, 32768) == 11       # short systems: a chain may be as short as two spike windows + a block
     assert L.spike_auto_partitions(128, 524288) == 182     # N/8 rows per GPU of the headline: 182 chains of 2880 rows, not 128 of 4096
     assert L.spike_auto_partitions(32, 2 ** 20) == 512     # BASELINE config 2: a chain keeps >= 64 K rows (measured: 512 chains 0.138 ms, 1024 0.162)

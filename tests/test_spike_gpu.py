@@ -471,3 +471,43 @@ def test_wide_bands_above_256(spike, oracle, torch_cuda, N, K, P):
     assert np.abs(sp.apply(oracle.band_matvec(band, u)) - u).max() <= 1e-10
     with pytest.raises(spike.SpikeError):
         spike.Spike(partitions=1).setup_band(oracle.gen_band(2048, 513, delta=1.2))
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+def test_wavefront_scan_four_rows_per_lane(spike, oracle, torch_cuda, K):
+    """K <= 3 (round 3): k_nscan_solve / k_nscan_sweep (a lane owns 4 consecutive rows, one 64-lane scan of K x K affine maps per
+    256 rows).  Against the oracle for: every register-resident length class (chains of <= 1024 / 2048 / 4096 rows) and the
+    two-launch form (longer chains), chain lengths that are no multiple of 4 or 256, vectors at 8-byte-only alignment (the
+    scalar load / store variant), both variants (the two-pass form sends corrections into the kernel), and against the
+    tile path / the one-row-per-lane scan it replaces (options narrow_scan_kmax / narrow_scan_rows)."""
+    torch = torch_cuda
+    for (N, P, sub) in [(1000, 1, "off"), (4099, 3, "off"), (2 ** 13 + 5, 4, "off"), (2 ** 14, 4, "off"), (20001, 2, "off"),
+                        (70001, 7, "on"), (2 ** 18 + 3, 0, "on")]:
+        band = oracle.gen_band(N, K, delta=1.1)
+        f = oracle.gen_vec(N, seed=N % 97)
+        for vname, variant in (("coupled", 1), ("decoupled", 0)):
+            sp = spike.Spike(partitions=P, variant=vname)
+            sp.set_option("subsplit", sub)
+            sp.setup_band(band)
+            i = sp.info()
+            x = sp.apply(f)
+            if P and sub == "off":
+                assert i.chains_local == P
+                assert _rel(x, oracle.Spike(band, P).apply(f, variant)) <= TOL, (N, P, vname)
+            elif variant == 1:
+                assert _rel(x, oracle.Spike(band, 1).apply(f, 0)) <= 1e-10, (N, P, vname)    # dominant: the exact solve to rounding
+            # vectors at an odd multiple of 8 bytes
+            fb = torch.zeros(N + 1, dtype=torch.float64, device="cuda"); fb[1:] = torch.from_numpy(f).cuda()
+            xb = torch.zeros(N + 1, dtype=torch.float64, device="cuda")
+            sp.apply(fb[1:], xb[1:])
+            torch.cuda.synchronize()
+            assert np.array_equal(xb[1:].cpu().numpy(), x), (N, P, vname, "alignment variant differs")
+            # the paths it replaces
+            alts = [("narrow_scan_kmax", 1)] if K > 1 else [("narrow_scan_rows", 1)]
+            for key, val in alts:
+                so = spike.Spike(partitions=P, variant=vname)
+                so.set_option("subsplit", sub); so.set_option(key, val); so.set_option("twist", "off")
+                so.setup_band(band)
+                assert _rel(so.apply(f), x) <= TOL, (N, P, vname, key)
+                so.close()
+            sp.close()

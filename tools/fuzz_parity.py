@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU box (not part of the suite: minutes of oracle time): random (N, K, partitions, dominance,
 variant) at sizes where sub-splitting and twisting engage, crossed with the round-3 options (twist, spike_fp32, iface_form,
 spike_tol), single rank and 2-3 thread ranks, against the oracle with the partitions the run really used.
-usage: python tools/fuzz_parity.py [cases] [seed]"""
+usage: python tools/fuzz_parity.py [cases] [seed] [K,K,...]   (a K list of 1..3 also varies the scan options and the sizes)"""
 import sys, os, threading, time; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import spike_petsc_amd as S
@@ -9,18 +9,24 @@ import oracle as O
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
 ks = [2, 3, 4, 7, 8, 12, 16, 24, 32, 33, 40, 64, 65, 96, 100, 128, 129, 192, 200, 256]
+if len(sys.argv) > 3: ks = [int(t) for t in sys.argv[3].split(",")]
+narrow = max(ks) <= 3
 bad = 0
 t00 = time.time()
 for case in range(ncases):
     K = int(rng.choice(ks))
     P = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 8, 16]))
-    logn = int(rng.integers(14, 19 if K <= 128 else 18))
+    logn = int(rng.integers(10 if narrow else 14, 19 if K <= 128 else 18))
     N = 2 ** logn + int(rng.choice([0, 0, 64, 16 * int(rng.integers(1, 40)), int(rng.integers(1, 500))]))
     delta = float(rng.choice([0.9, 1.0, 1.2, 1.2, 1.5]))
     variant = str(rng.choice(["coupled", "coupled", "decoupled"]))
     opts = {"twist": str(rng.choice(["auto", "auto", "off"])), "spike_fp32": str(rng.choice(["auto", "off"])),
             "iface_form": str(rng.choice(["matrix", "staged"])), "spike_tol": str(rng.choice(["1e-13", "1e-16", "1e-12"]))}
+    if narrow:
+        opts["narrow_scan_rows"] = str(rng.choice(["1", "4", "4"]))
+        opts["narrow_scan_kmax"] = str(rng.choice(["1", "3", "3", "3"]))
     G = int(rng.choice([1, 1, 1, 2, 3]))
+    if narrow and P > (N // 64) // G: P = max(1, (N // 64) // G)   # every rank needs a 64-row block per partition
     band = O.gen_band(N, K, seed=1000 + case, delta=delta)
     f = O.gen_vec(N, seed=50 + case)
     info = {}

@@ -107,7 +107,11 @@ const char *spike_last_error(spike_handle h);
  *       "twist" ("auto"|"off": two-ended factorisation of chain pairs where stored spikes apply; same preconditioner),
  *       "spike_tol" default 1e-13 since round 3, "spike_fp32" ("auto"|"off": far part of the stored spikes in fp32),
  *       "iface_form" ("matrix"|"staged": one-stage or three-stage interface solves; same result to rounding),
- *       "correct_threads" (64|128|256: workgroup size of the spike correction, measurement option)      */
+ *       "correct_threads" (64|128|256: workgroup size of the spike correction, measurement option),
+ *       "narrow_scan_kmax" (1..3, default 3: half-bandwidths up to this are solved by the wavefront scan -- no tiles, the
+ *        algorithmic (2K+3)*8 bytes per row -- above it by the tile sweeps; same preconditioner),
+ *       "narrow_scan_rows" (1|4, default 4: K = 1 through the one-row-per-lane scan of round 2 or the four-rows-per-lane
+ *        kernels; K = 2, 3 always four)      */
 int spike_set_option(spike_handle h, const char *key, const char *value);
 /* HIP stream (hipStream_t) all device work of this handle is issued on; NULL = default stream */
 int spike_set_stream(spike_handle h, void *hip_stream);

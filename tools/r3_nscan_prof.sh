@@ -1,12 +1,9 @@
 #!/bin/bash
-# narrow bands (K = 1, 2, 3) through the four-rows-per-lane scan: twisted-tile test file, bench lines, kernel stats
+# narrow bands (K = 1, 2, 3) through the four-rows-per-lane scan: bench lines, kernel stats, A/B against the paths it replaces
 set -e
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/prof_nscan
 mkdir -p $OUT
-cd $ROOT
-timeout -k 10 600 python3 -m pytest tests/test_twisted_gpu.py -x -q > $OUT/twisted_tests.log 2>&1 || { tail -20 $OUT/twisted_tests.log; exit 1; }
-tail -2 $OUT/twisted_tests.log
 cd /tmp && export TMPDIR=/tmp
 for cfg in "1 16777216" "2 8388608" "3 8388608" "2 16777216"; do
   set -- $cfg
@@ -16,5 +13,9 @@ for cfg in "1 16777216" "2 8388608" "3 8388608" "2 16777216"; do
   rm -rf $OUT/stats_k$1_n$2
   echo "K=$1 N=$2 done" >> $OUT/progress.log
 done
+python3 $ROOT/tools/ab_apply.py 8388608 2 0 "nscan:" "tiles:narrow_scan_kmax=1" 2>&1 | grep -v amdgpu > $OUT/ab_k2.log
+python3 $ROOT/tools/ab_apply.py 8388608 3 0 "nscan:" "tiles:narrow_scan_kmax=1" 2>&1 | grep -v amdgpu > $OUT/ab_k3.log
+python3 $ROOT/tools/ab_apply.py 16777216 1 0 "rows4:" "rows1:narrow_scan_rows=1" 2>&1 | grep -v amdgpu > $OUT/ab_k1.log
+cat $OUT/ab_k*.log | cut -c1-130
 python3 $ROOT/tools/show_bench.py $OUT/nb_k*_n*[0-9].json
 for f in $OUT/k*_kernel_stats.csv; do echo $f; head -6 $f | cut -c1-160; done

@@ -100,8 +100,8 @@ const char *spike_last_error(spike_handle h);
  *       "profile" (0|1: record HIP events around the sweep launches),
  *       "overlap_exchange" ("on"|"off", default on: several ranks run the tip exchange and the rank-boundary interfaces on
  *        a second stream beside the local coupling work; same bits either way),
- *       "small_coupling_kmax" (0..8, default 1: half-bandwidths up to this take the two-launch narrow-band coupling step
- *        on one rank; same preconditioner),
+ *       "small_coupling_kmax" (0..8, default 3: half-bandwidths up to this take the one-launch narrow-band coupling step
+ *        on one rank (K = 2, 3: behind the one-launch scan only); same preconditioner),
  *       "gmres_cgs_refinement_type" ("refine_never"|"refine_ifneeded"|"refine_always": the Gram-Schmidt refinement of
  *        spike_gmres, names and default (never) of PETSc's -ksp_gmres_cgs_refinement_type),
  *       "twist" ("auto"|"off": two-ended factorisation of chain pairs where stored spikes apply; same preconditioner),

@@ -198,7 +198,7 @@ struct spike_handle_s {
     int nif_local_all = 0;                                // interfaces between this rank's chains
     int scan_kmax = DEFAULT_SCAN_KMAX, scan_rows = DEFAULT_SCAN_ROWS;   // wavefront scan for K <= scan_kmax (options narrow_scan_kmax / narrow_scan_rows)
     int64_t scan_lds = 0;                                 // row stride of the k_nscan_* coefficient arrays
-    int small_kmax = 1;                                   // k_couple_small for K <= this (measured: pays at K = 1 only; option small_coupling_kmax)
+    int small_kmax = 3;                                   // one-launch coupling step for K <= this (option small_coupling_kmax; K = 2, 3: behind the fused scan only; the generic K <= 8 kernel gains nothing)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
     // (the 26 KiB of interface descriptors at 256 chains is) makes the FIRST such copy of a process build the runtime's
@@ -761,6 +761,15 @@ static bool scan_fused(spike_handle h)
     return h->cfg.scan && h->max_chain_rows <= (h->cfg.nscan ? nscan_max_rows(h->K) : 64 * 64);
 }
 
+// the narrow-band coupling step in one launch (launch_couple_small): one rank, ordinary chains; K = 1 always, K = 2, 3 when
+// the fused scan hands over the chain-end values, wider only on request (option small_coupling_kmax > 3)
+static bool small_coupling(spike_handle h, bool multi)
+{
+    const int K = h->K;
+    if (K < 1 || K > h->small_kmax || multi || h->twisted) return false;
+    return K == 1 || K > 3 || scan_fused(h);
+}
+
 // one forward+backward pass over all chains: out = blockdiag(A_p)^{-1} (in - corrections)
 struct SubChains {  // a sub-range of row blocks of every chain (setup: spikes are computed only where they live)
     const ChainDesc *chains = nullptr;
@@ -1311,7 +1320,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         }
         // ---- mixed precision: the far part of every window goes to fp32 (k_spike_correct comment)
         h->spike_m1 = m;
-        const bool small_path = K >= 1 && K <= h->small_kmax && !multi && !tw;   // k_couple_small reads plain fp64 windows
+        const bool small_path = small_coupling(h, multi);   // k_couple_small reads plain fp64 windows
         if (m > 0 && h->spike_fp32 && !small_path && m % 64 == 0) {
             int m1 = (int)(((int64_t)(extent32 * 1.06) + 64 + 63) / 64 * 64);
             if (m1 < m && m - m1 >= 128) {
@@ -1648,10 +1657,10 @@ static int apply_dev(spike_handle h, const double *x, double *y)
             HIPCHK(hipMemsetAsync(h->dCorrBot, 0, sizeof(double) * P * K, st));
         }
     }
-    // K = 1 (option small_coupling_kmax: up to 8 -- measured 2026-10: K = 2..8 gain nothing, their chains carry 200-row spike
-    // windows and the general kernels are as fast), one rank, every interface coupled, windows that do not overlap: the small
-    // coupling step (two tiny launches)
-    if (K >= 1 && K <= h->small_kmax && !multi && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
+    // K <= 3 (small_coupling(); option small_coupling_kmax: up to 8 -- the generic K <= 8 kernel measured no gain, their chains
+    // carry 200-row spike windows and the general kernels are as fast), one rank, every interface coupled, windows that do not
+    // overlap: the coupling step in one launch
+    if (small_coupling(h, multi) && coupled && h->spike_m > 0 && 2 * h->spike_m <= h->min_chain_rows && h->dTips1 != nullptr &&
         h->nif_local_all == P - 1 && !h->twisted && h->spike_m1 == h->spike_m)
         return launch_couple_small(P, K, h->spike_m, h->dChains, h->dTips1, h->dWT, h->dST, h->dVT, h->dWf, h->dVf, y, st,
                                    /*tips_ready=*/scan_fused(h)) == hipSuccess

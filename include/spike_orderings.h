@@ -17,6 +17,13 @@ extern "C" {
 int spike_mc64_job5(int64_t n, const int64_t *colptr, const int64_t *rowind, const double *val, int64_t *perm,
                     double *u, double *v, int64_t *num);
 int spike_awbm(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *perm, double *sr, double *sc);
+/* the same matching for a matrix distributed by rows (MatComputeMatching_MPIAIJ, src/wbm.c:201-440; csrc/host/awbm_dist.c):
+ * every rank (1) computes its contribution to the per-column minima over all N columns, (2) the CALLER reduces those with MIN
+ * over the ranks (MPI_Allreduce(..., MPI_MIN, comm) in a PETSc binding -- the reference's own "TODO ... MPI_MIN", :270), (3)
+ * every rank matches its own rows inside its diagonal block: perm over the local indices, perm[match[c]] = c */
+int spike_awbm_dist_rowmin(int64_t n_local, int64_t N, const int64_t *ia, const int64_t *ja, const double *a, double *umin);
+int spike_awbm_dist_match(int64_t n_local, int64_t row0, int64_t N, const int64_t *ia, const int64_t *ja, const double *a,
+                          const double *u, int64_t *perm, double *sr, double *sc);
 int spike_fiedler_order(int64_t n, const int64_t *ia, const int64_t *ja, const double *a, int64_t *order, double *vec);
 /* use_device != 0 and a HIP device present: the LOBPCG refinement of the large multilevel levels runs on the GPU
  * (libspike_mi355: spike_fd_*), with a bit-identical permutation */

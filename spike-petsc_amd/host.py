@@ -28,7 +28,7 @@ HOST_SYMBOLS = [
     "KSPAppendOptionsPrefix", "KSPSetOperators", "KSPGetPC", "KSPSetTolerances", "KSPSetFromOptions", "KSPSetUp",
     "KSPSolve", "KSPGetConvergedReason", "KSPGetIterationNumber", "KSPGetResidualNorm", "KSPView", "KSPDestroy",
     "KSPCreate_Reorder", "KSPCreate_GMRES", "KSPReorderGetOrdering", "spike_mc64_job5", "spike_fiedler_order", "spike_fiedler_order_ex", "spike_fiedler_halves_order", "MatGetOrdering_FiedlerHalves",
-    "spike_profile_bandwidth", "spike_awbm", "spike_mc64_job5_i32", "spike_awbm_i32", "spike_fiedler_order_i32", "spike_rcm_order_i32", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
+    "spike_profile_bandwidth", "spike_awbm", "spike_awbm_dist_rowmin", "spike_awbm_dist_match", "spike_mc64_job5_i32", "spike_awbm_i32", "spike_fiedler_order_i32", "spike_rcm_order_i32", "MatLoad", "MatLoadMatrixMarket", "MatViewMatrixMarket", "MatViewBinary",
 ]
 
 _L = None
@@ -97,6 +97,8 @@ def lib():
     L.KSPReorderGetOrdering.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.spike_mc64_job5.argtypes = [i64, i64p, i64p, dp, i64p, dp, dp, i64p]
     L.spike_awbm.argtypes = [i64, i64p, i64p, dp, i64p, dp, dp]
+    L.spike_awbm_dist_rowmin.argtypes = [i64, i64, i64p, i64p, dp, dp]
+    L.spike_awbm_dist_match.argtypes = [i64, i64, i64, i64p, i64p, dp, dp, i64p, dp, dp]
     L.MatLoad.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.MatLoadMatrixMarket.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.MatViewMatrixMarket.argtypes = [vp, C.c_char_p]
@@ -213,6 +215,42 @@ def awbm(n, ia, ja, a):
     if rc:
         raise HostError("spike_awbm failed (%d)" % rc)
     return perm
+
+
+def awbm_dist(row0, N, ia, ja, a, group=None, scalings=False):
+    """The approximate matching of a matrix distributed by rows (reference: MatComputeMatching_MPIAIJ, src/wbm.c:201-440):
+    this rank owns rows [row0, row0 + n_local) in CSR with GLOBAL column indices.  Collective over `group` (torch.distributed;
+    None with no initialised process group = one rank): the per-column minima are reduced with MIN -- the operation the
+    reference's comment at :270 asks for.  Returns the rank's local permutation (perm[match[c]] = c) and the reduced u."""
+    ia, ja, a = _i(ia), _i(ja), _d(a)
+    n_local = len(ia) - 1
+    u = np.empty(N, dtype=np.float64)
+    rc = lib().spike_awbm_dist_rowmin(n_local, N, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp), u.ctypes.data_as(dp))
+    if rc:
+        raise HostError("spike_awbm_dist_rowmin failed (%d)" % rc)
+    try:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        multi = False
+    if multi:
+        import torch
+        t = torch.from_numpy(u)
+        if dist.get_backend(group) == "nccl":        # RCCL reduces device tensors
+            t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            u = t.cpu().numpy()
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    perm = np.zeros(n_local, dtype=np.int64)
+    sr = np.zeros(n_local) if scalings else None
+    sc = np.zeros(n_local) if scalings else None
+    rc = lib().spike_awbm_dist_match(n_local, row0, N, ia.ctypes.data_as(i64p), ja.ctypes.data_as(i64p), a.ctypes.data_as(dp),
+                                     u.ctypes.data_as(dp), perm.ctypes.data_as(i64p),
+                                     sr.ctypes.data_as(dp) if scalings else None, sc.ctypes.data_as(dp) if scalings else None)
+    if rc:
+        raise HostError("spike_awbm_dist_match failed (%d)" % rc)
+    return (perm, u, sr, sc) if scalings else (perm, u)
 
 
 def rcm_order(n, ia, ja):

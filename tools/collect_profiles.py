@@ -11,7 +11,8 @@ tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = "profiles"
 for name in ["bench", "n2097152", "n1048576", "n524288", "c2", "fiedler"]:
-    f = glob.glob(os.path.join(src, "stats_" + name, "*", "*_kernel_stats.csv")) or glob.glob(os.path.join(src, name + "_kernel_stats.csv"))
+    # the flat copy made ON the box first: the local stats_* directories accumulate the runs of earlier captures
+    f = glob.glob(os.path.join(src, name + "_kernel_stats.csv")) or glob.glob(os.path.join(src, "stats_" + name, "*", "*_kernel_stats.csv"))
     if f:
         shutil.copy(f[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
 for name in ["bench_line.json", "bench_line_under_rocprof.json", "pmc_summary.json", "rank_n2097152.json", "rank_n1048576.json",

@@ -932,7 +932,7 @@ __device__ __forceinline__ bool nscan_chain(const NScanArgs &s, NScanChain &c)
 template <int KK, bool AL>
 __device__ __forceinline__ void nscan_load_fwd(NScanRaw<KK> &q, const NScanArgs &s, const NScanChain &c, int it, int lane)
 {
-    const int left = c.nrows - it * NSCAN_BLK;
+    const int left = it < 0 ? 0 : c.nrows - it * NSCAN_BLK;   // (a block past the end: negative -> empty range)
     const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
     const int voff = 32 * lane;
 #pragma unroll
@@ -968,7 +968,7 @@ __device__ __forceinline__ void nscan_use_fwd(NScanRaw<KK> &q, const NScanArgs &
 template <int KK>
 __device__ __forceinline__ void nscan_load_bwd(NScanRaw<KK> &q, const NScanArgs &s, const NScanChain &c, int it, int lane)
 {
-    const int left = c.nrows - it * NSCAN_BLK;
+    const int left = it < 0 ? 0 : c.nrows - it * NSCAN_BLK;
     const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
     const int voff = 32 * (63 - lane);
 #pragma unroll
@@ -1067,10 +1067,12 @@ __global__ __launch_bounds__(256) void k_nscan_solve(NScanArgs s)
 }
 
 // one direction per launch, any chain length: forward writes D^{-1} L^{-1} r to `out`, backward solves with the unit upper
-// factor (in = the forward result)
+// factor (in = the forward result).  Three blocks in flight per wave (ring slots = step mod 3, the loop unrolled by 3 so that the
+// slot is a compile-time index); loads unconditional as in k_nscan_solve (a block outside the chain: zero-length descriptor).
 template <int KK, bool REV, bool AL, int TAG>
 __global__ __launch_bounds__(256) void k_nscan_sweep(NScanArgs s)
 {
+    constexpr int NSW = 3;
     const int lane = threadIdx.x & 63;
     NScanChain c;
     if (!nscan_chain(s, c)) return;
@@ -1078,48 +1080,52 @@ __global__ __launch_bounds__(256) void k_nscan_sweep(NScanArgs s)
     double S[KK];
 #pragma unroll
     for (int e = 0; e < KK; ++e) S[e] = 0.0;
-    if (!REV) {
-        NScanRaw<KK> cur, nxt;
-        double dvc[4], dvn[4];
-        auto load = [&](NScanRaw<KK> &q, double (&dv)[4], int it) {
-            nscan_load_fwd<KK, AL>(q, s, c, it, lane);
-            nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.dinv + c.row0 + (int64_t)it * NSCAN_BLK, c.nrows - it * NSCAN_BLK, true), 32 * lane, dv);
-        };
-        load(cur, dvc, 0);
-        for (int it = 0; it < nblk; ++it) {
-            if (it + 1 < nblk) load(nxt, dvn, it + 1);
-            NScanBlock<KK> b;
-            nscan_use_fwd<KK>(cur, s, c, it, lane);
-            b.prepare(cur.a, cur.r);
-            double v[4];
-            b.finish(S, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= dvc[j];
-            const int left = c.nrows - it * NSCAN_BLK;
-            const __amdgpu_buffer_rsrc_t ro = nscan_rsrc(s.out + c.row0 + (int64_t)it * NSCAN_BLK, left, false);
-            if (AL && !(left < NSCAN_BLK && (left & 3))) nscan_bstore4<true>(ro, 32 * lane, v);
-            else nscan_bstore4<false>(ro, 32 * lane, v);
-            if (it + 1 < nblk) {
-                cur = nxt;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dvc[j] = dvn[j];
-            }
+    NScanRaw<KK> q[NSW];
+    double x[NSW][4];   // forward: 1 / diag; backward: the forward result
+    // step t handles block t (forward) or nblk - 1 - t (backward)
+    auto load = [&](int slot, int t) {
+        const int it = REV ? nblk - 1 - t : t;
+        const int left = (it < 0 || it >= nblk) ? 0 : c.nrows - it * NSCAN_BLK;
+        const int64_t g = c.row0 + (int64_t)it * NSCAN_BLK;
+        if (!REV) {
+            nscan_load_fwd<KK, AL>(q[slot], s, c, it, lane);
+            nscan_bload4<true, NSCAN_AUX_NT>(nscan_rsrc(s.dinv + g, left, true), 32 * lane, x[slot]);
+        } else {
+            nscan_load_bwd<KK>(q[slot], s, c, it, lane);   // (1 / diag comes along unused: the forward launch has applied it)
+            nscan_bload4<AL, 0>(nscan_rsrc(s.in + g, left, AL), 32 * (63 - lane), x[slot]);
         }
-    } else {
-        for (int it = nblk - 1; it >= 0; --it) {
-            NScanRaw<KK> q;
-            double t[4], r[4], a[KK][4], dv[4];
-            nscan_load_bwd<KK>(q, s, c, it, lane);   // (1 / diag: not needed here, the forward launch has applied it)
-            const int left = c.nrows - it * NSCAN_BLK;
-            nscan_bload4<AL, 0>(nscan_rsrc(s.in + c.row0 + (int64_t)it * NSCAN_BLK, left, AL), 32 * (63 - lane), t);
-            nscan_use_bwd<KK>(q, c, it, lane, a, dv);
+    };
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = (4 * (63 - lane) + 3 - j < left) ? t[3 - j] : 0.0;
-            NScanBlock<KK> b;
-            b.prepare(a, r);
-            double v[4];
-            b.finish(S, v);
-            nscan_store_bwd<KK, AL>(v, s, c, it, lane);
+    for (int j = 0; j < NSW; ++j) load(j, j);
+    for (int t0 = 0; t0 < nblk; t0 += NSW) {
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) {
+            const int t = t0 + j;
+            if (t < nblk) {
+                const int it = REV ? nblk - 1 - t : t;
+                const int left = c.nrows - it * NSCAN_BLK;
+                NScanBlock<KK> b;
+                double v[4];
+                if (!REV) {
+                    nscan_use_fwd<KK>(q[j], s, c, it, lane);
+                    b.prepare(q[j].a, q[j].r);
+                    b.finish(S, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= x[j][e];
+                    const __amdgpu_buffer_rsrc_t ro = nscan_rsrc(s.out + c.row0 + (int64_t)it * NSCAN_BLK, left, false);
+                    if (AL && !(left < NSCAN_BLK && (left & 3))) nscan_bstore4<true>(ro, 32 * lane, v);
+                    else nscan_bstore4<false>(ro, 32 * lane, v);
+                } else {
+                    double a[KK][4], dv[4], r[4];
+                    nscan_use_bwd<KK>(q[j], c, it, lane, a, dv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = (4 * (63 - lane) + 3 - e < left) ? x[j][3 - e] : 0.0;
+                    b.prepare(a, r);
+                    b.finish(S, v);
+                    nscan_store_bwd<KK, AL>(v, s, c, it, lane);
+                }
+            }
+            load(j, t + NSW);
         }
     }
 }

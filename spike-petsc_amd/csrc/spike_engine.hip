@@ -2134,7 +2134,7 @@ extern "C" int spike_get_info(spike_handle h, spike_info *o)
 {
     if (!h || !o) return SPIKE_ERR_ARG;
     memset(o, 0, sizeof *o);
-    o->n_local = h->n; o->n_global = h->n_global; o->row0 = h->row0; o->K = h->K; o->Kp = h->cfg.KP();
+    o->n_local = h->n; o->n_global = h->n_global; o->row0 = h->row0; o->K = h->K; o->Kp = h->cfg.scan ? h->K : h->cfg.KP();
     o->P_local = h->P_user; o->P_global = h->P_user * h->nranks; o->variant = h->variant;
     o->chains_local = h->P;
     o->rows_per_block = h->cfg.R; o->waves_per_chain = h->cfg.NW; o->nranks = h->nranks; o->rank = h->rank;
@@ -2155,9 +2155,10 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
     snprintf(buf, len,
              "  SPIKE (MI355X): n = %lld (global %lld), K = %d (streamed %d), partitions = %d, variant = %s\n"
              "    rows/block = %d, waves/chain = %d, boosted pivots = %lld, setup = %.2f ms, ranks = %d, stored spike rows = %d (%d in fp64), chains = %d%s\n",
-             (long long)h->n, (long long)h->n_global, h->K, h->cfg.KP(), h->P_user,
-             h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.R, h->cfg.NW,
-             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->spike_m1, h->P, h->twisted ? " (twisted pairs)" : "");
+             (long long)h->n, (long long)h->n_global, h->K, h->cfg.scan ? h->K : h->cfg.KP(), h->P_user,
+             h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.nscan ? NSCAN_ROWS_PER_BLOCK : h->cfg.R, h->cfg.NW,
+             (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->spike_m1, h->P,
+             h->twisted ? " (twisted pairs)" : h->cfg.nscan ? " (wavefront scan, 4 rows per lane)" : h->cfg.scan ? " (wavefront scan)" : "");
     return SPIKE_OK;
 }
 

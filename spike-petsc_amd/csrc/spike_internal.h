@@ -83,6 +83,7 @@ struct IfaceDesc {
     double *xt_out;    // K doubles: x^(t), top-tip solution of the lower partition, or null
 };
 
+constexpr int NSCAN_ROWS_PER_BLOCK = 256;   // k_nscan_*: 64 lanes x 4 rows
 constexpr int DEFAULT_SCAN_KMAX = 3, DEFAULT_SCAN_ROWS = 4;   // (handle options narrow_scan_kmax / narrow_scan_rows)
 bool pick_cfg(int K, SweepCfg *cfg, int scan_kmax = DEFAULT_SCAN_KMAX, int scan_rows = DEFAULT_SCAN_ROWS);
 bool sweep_shape_exists(const SweepCfg &cfg, int dpw, int nw, int pf);

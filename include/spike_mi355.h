@@ -110,6 +110,9 @@ const char *spike_last_error(spike_handle h);
  *       "correct_threads" (64|128|256: workgroup size of the spike correction, measurement option),
  *       "narrow_scan_kmax" (1..3, default 3: half-bandwidths up to this are solved by the wavefront scan -- no tiles, the
  *        algorithmic (2K+3)*8 bytes per row -- above it by the tile sweeps; same preconditioner),
+ *       "workspace_cache" ("on"|"off", default on: the device blocks of a handle are recycled by size between its setups --
+ *        a refactorisation on the same handle makes no hipMalloc / hipFree calls; idle blocks a whole setup did not use are
+ *        released at its end, spike_reset / spike_destroy release everything; off: every setup allocates and frees),
  *       "narrow_scan_rows" (1|4, default 4: K = 1 through the one-row-per-lane scan of round 2 or the four-rows-per-lane
  *        kernels; K = 2, 3 always four)      */
 int spike_set_option(spike_handle h, const char *key, const char *value);

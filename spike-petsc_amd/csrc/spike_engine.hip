@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace spike;
@@ -118,6 +119,15 @@ static std::mutex g_local_mutex;
 static std::map<int, std::shared_ptr<LocalComm>> g_local;
 
 // ---- handle ---------------------------------------------------------------------------------------
+// device blocks a handle recycles between setups (the allocator further down explains)
+struct DevCache {
+    struct Idle { void *p; int gen; };
+    std::multimap<size_t, Idle> idle;
+    int gen = 0;          // setup counter of the owning handle
+    bool enabled = true;
+    int64_t hits = 0, misses = 0;
+};
+
 struct spike_handle_s {
     // options
     int opt_partitions = 0;
@@ -198,6 +208,7 @@ struct spike_handle_s {
     int nif_local_all = 0;                                // interfaces between this rank's chains
     int scan_kmax = DEFAULT_SCAN_KMAX, scan_rows = DEFAULT_SCAN_ROWS;   // wavefront scan for K <= scan_kmax (options narrow_scan_kmax / narrow_scan_rows)
     int64_t scan_lds = 0;                                 // row stride of the k_nscan_* coefficient arrays
+    DevCache cache;                                       // device blocks recycled between setups (option workspace_cache)
     int small_kmax = 3;                                   // one-launch coupling step for K <= this (option small_coupling_kmax; K = 2, 3: behind the fused scan only; the generic K <= 8 kernel gains nothing)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
     // Pinned staging area for setup's descriptor uploads.  A pageable source above the runtime's small-copy threshold
@@ -253,12 +264,91 @@ static int fail(spike_handle h, int code, const char *fmt, ...)
         if (r_ != 0) return fail(h, SPIKE_ERR_COMM, "%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
     } while (0)
 
+// ---- device memory of a handle: recycled between setups -------------------------------------------------------------
+// hipMalloc / hipFree of multi-GB blocks are expensive and erratic on this stack (measured at the headline size: 80 calls per
+// setup, usually ~5 ms in total -- but 0.25 s in a process's first setup and 1.0 s for the 8.6 GB band copy of a SECOND setup
+// right after the first one's blocks went back to the driver; K = 256: up to 5 s, tools/setup_repeat_k256.py).  A solver that
+// refactors (PCSetUp per time step or Newton step, the reference's use: matbanded.c:178) asks for the same block sizes
+// every time, so blocks a handle gives back are kept by exact size and handed out again:
+//   * dalloc() inside a setup (t_cache set) takes an idle block of that size if there is one, else hipMalloc (on failure:
+//     all idle blocks go back to the driver, one retry);
+//   * dfree() of a block that came from a cache returns it there; anything else goes to hipFree;
+//   * idle blocks a whole setup did not touch are released at its end (a changed size or layout does not pile up memory);
+//     spike_reset / spike_destroy release everything; option "workspace_cache" = "off": no caching at all.
+// The idle blocks are memory the process holds between setups (scratch of the factorisation: about one band, on top of
+// band + factors that are live anyway).
+struct DevBlock { size_t bytes; DevCache *owner; };
+static std::mutex g_blocks_mu;
+static std::unordered_map<void *, DevBlock> g_blocks;   // every live block that came through a cache
+static thread_local DevCache *t_cache = nullptr;        // the cache of the handle whose setup runs on this thread
+
+// SPIKE_SETUP_TRACE: time spent inside hipMalloc / hipFree during setup (printed with the phase times)
+static thread_local bool g_alloc_trace = false;
+static thread_local double g_alloc_ms = 0.0;
+static thread_local int g_alloc_n = 0;
+
+static void cache_flush(DevCache *c, int older_than_gen)   // release idle blocks with gen < older_than_gen (INT_MAX: all)
+{
+    for (auto it = c->idle.begin(); it != c->idle.end();) {
+        if (it->second.gen < older_than_gen) {
+            { std::lock_guard<std::mutex> lk(g_blocks_mu); g_blocks.erase(it->second.p); }
+            (void)hipFree(it->second.p);
+            it = c->idle.erase(it);
+        } else ++it;
+    }
+}
+
+static hipError_t dalloc_bytes(void **p, size_t bytes)
+{
+    *p = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    DevCache *c = (t_cache && t_cache->enabled) ? t_cache : nullptr;
+    if (c) {
+        auto it = c->idle.find(bytes);
+        if (it != c->idle.end()) { *p = it->second.p; c->idle.erase(it); ++c->hits; return hipSuccess; }   // (stays registered)
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && c && !c->idle.empty()) {   // out of memory with idle blocks in hand: give them back, once more
+        (void)hipGetLastError();
+        cache_flush(c, INT_MAX);
+        e = hipMalloc(p, bytes);
+    }
+    if (g_alloc_trace) { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_n; }
+    if (e == hipSuccess && c) {
+        ++c->misses;
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        g_blocks[*p] = DevBlock{bytes, c};
+    }
+    return e;
+}
+
 template <class T>
 static hipError_t dalloc(T **p, size_t count)
 {
-    *p = nullptr;
-    if (count == 0) count = 1;
-    return hipMalloc((void **)p, count * sizeof(T));
+    return dalloc_bytes((void **)p, (count ? count : 1) * sizeof(T));
+}
+
+struct CacheScope {
+    DevCache *prev;
+    explicit CacheScope(DevCache *c) : prev(t_cache) { t_cache = c; }
+    ~CacheScope() { t_cache = prev; }
+};
+
+static void dfree(void *p)
+{
+    if (!p) return;
+    DevBlock b{0, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        auto it = g_blocks.find(p);
+        if (it != g_blocks.end()) { b = it->second; if (!b.owner->enabled) g_blocks.erase(it); }
+    }
+    if (b.owner && b.owner->enabled) { b.owner->idle.emplace(b.bytes, DevCache::Idle{p, b.owner->gen}); return; }
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipFree(p);
+    if (g_alloc_trace) { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_n; }
 }
 
 // true when the exchange steps must run: several ranks, or the one-rank RCCL self-test (spike_comm_init with nranks = 1
@@ -334,20 +424,20 @@ struct TmpPool {
     void release(T *&p)  // free one buffer early (the LU scratch is as large as the band)
     {
         for (auto &q : ptrs)
-            if (q == (void *)p) { (void)hipFree(q); q = nullptr; }
+            if (q == (void *)p) { dfree(q); q = nullptr; }
         p = nullptr;
     }
     void release_all()
     {
         for (auto &q : ptrs)
-            if (q) { (void)hipFree(q); q = nullptr; }
+            if (q) { dfree(q); q = nullptr; }
     }
     ~TmpPool() { release_all(); }
 };
 
 static void free_factors(spike_handle h)
 {
-    auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    auto F = [](auto *&p) { if (p) { dfree((void *)p); p = nullptr; } };
     if (h->ownA) F(h->dA); else h->dA = nullptr;
     h->ownA = false;
     if (h->dChainsV == h->dChains) h->dChainsV = nullptr;   // an alias unless twisted
@@ -398,6 +488,7 @@ extern "C" int spike_create(spike_handle *out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { *out = nullptr; return SPIKE_ERR_HIP; }
     *out = new spike_handle_s();
+    if (const char *e = getenv("SPIKE_WORKSPACE_CACHE")) (*out)->cache.enabled = !(strcmp(e, "off") == 0 || strcmp(e, "0") == 0);   // measurement knob; the option is workspace_cache
     (*out)->pinCap = (size_t)1 << 20;   // the pinned staging area of upload(), made here so that no setup pays for it
     if (hipHostMalloc((void **)&(*out)->hPin, (*out)->pinCap, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (*out)->hPin = nullptr; (*out)->pinCap = 0; }
     return SPIKE_OK;
@@ -408,6 +499,7 @@ extern "C" int spike_reset(spike_handle h)
     if (!h) return SPIKE_ERR_ARG;
     (void)hipStreamSynchronize(h->stream);
     free_factors(h);
+    cache_flush(&h->cache, INT_MAX);   // "drop the factors": the memory goes back to the driver
     return SPIKE_OK;
 }
 
@@ -417,6 +509,10 @@ extern "C" int spike_destroy(spike_handle h)
     if (!h) return SPIKE_ERR_ARG;
     spike_reset(h);
     spike_clear_operator(h);
+    {   // no registered block may point at a cache that is about to go away
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        for (auto it = g_blocks.begin(); it != g_blocks.end();) it = it->second.owner == &h->cache ? g_blocks.erase(it) : std::next(it);
+    }
     if (h->comm && g_rccl.ok()) g_rccl.CommDestroy(h->comm);
     for (auto &e : h->evs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->evFork) (void)hipEventDestroy(h->evFork);
@@ -455,6 +551,10 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
         else return fail(h, SPIKE_ERR_ARG, "iface_form is 'matrix' or 'staged'");
     }
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "workspace_cache") {
+        h->cache.enabled = !(v == "off" || v == "0");
+        if (!h->cache.enabled) cache_flush(&h->cache, INT_MAX);
+    }
     else if (k == "narrow_scan_kmax") { h->scan_kmax = atoi(val); if (h->scan_kmax < 1 || h->scan_kmax > 3) return fail(h, SPIKE_ERR_ARG, "narrow_scan_kmax must be in 1..3"); }
     else if (k == "narrow_scan_rows") { h->scan_rows = atoi(val); if (h->scan_rows != 1 && h->scan_rows != 4) return fail(h, SPIKE_ERR_ARG, "narrow_scan_rows is 1 or 4"); }
     else if (k == "small_coupling_kmax") { h->small_kmax = atoi(val); if (h->small_kmax < 0 || h->small_kmax > 8) return fail(h, SPIKE_ERR_ARG, "small_coupling_kmax must be in 0..8"); }
@@ -512,7 +612,7 @@ extern "C" int spike_comm_init(spike_handle h, int nranks, int rank, const char 
         std::vector<double> got((size_t)(3 + nranks), 0.0);
         hipError_t he = hipStreamSynchronize(nullptr);
         if (he == hipSuccess) he = hipMemcpy(got.data(), d, sizeof(double) * (size_t)(3 + nranks), hipMemcpyDeviceToHost);
-        (void)hipFree(d);
+        dfree(d);
         bool ok = rs == 0 && rm == 0 && rg == 0 && he == hipSuccess && got[0] == (double)nranks && got[1] == (double)(nranks - 1);
         for (int r = 0; r < nranks && ok; ++r) ok = got[(size_t)(3 + r)] == (double)(r + 1);
         if (!ok) {
@@ -886,12 +986,15 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     SweepCfg cfg;
     if (!pick_cfg(K, &cfg, h->scan_kmax, h->scan_rows)) return fail(h, SPIKE_ERR_ARG, "half-bandwidth %d not supported (0..512)", K);
     (void)hipStreamSynchronize(h->stream);
+    ++h->cache.gen;
+    CacheScope cache_scope(&h->cache);   // allocations of this setup come from / go back to the handle's idle blocks
     free_factors(h);
     TmpPool tmp;
     const auto t_start = std::chrono::steady_clock::now();
     h->pinOff = 0;   // every copy of the previous setup has completed (setup ends with a synchronisation)
     // SPIKE_SETUP_TRACE=1: wall time of every setup phase on stderr (synchronises the stream at phase boundaries)
     const bool trace = getenv("SPIKE_SETUP_TRACE") != nullptr;
+    g_alloc_trace = trace; g_alloc_ms = 0.0; g_alloc_n = 0;
     auto t_mark = t_start;
     RoctxRange setup_range("spike_setup");
     auto mark = [&](const char *what) {
@@ -1313,7 +1416,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
             // anything of weight left at the far edge of the window?  then the spikes do not decay: keep the re-solve variant
             // (a window that covers every chain completely holds the full spikes: nothing to check)
             if (m < nmax && stat[1] > 1e3 * h->spike_tol * stat[0]) {
-                (void)hipFree(h->dWf); if (h->dVf) (void)hipFree(h->dVf);
+                dfree(h->dWf); if (h->dVf) dfree(h->dVf);
                 h->dWf = h->dVf = nullptr;
                 m = 0;
             }
@@ -1340,11 +1443,11 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
                 HIPCHK(hipStreamSynchronize(st));
                 // the probe looked at two columns per side; the split kernel saw every entry that went to fp32
                 if (peak[2] <= 4.0 * FP32_LEVEL * peak[0]) {
-                    (void)hipFree(h->dWf); if (h->dVf) (void)hipFree(h->dVf);
+                    dfree(h->dWf); if (h->dVf) dfree(h->dVf);
                     h->dWf = p64[0]; h->dVf = p64[1]; h->dWf32 = p32[0]; h->dVf32 = p32[1];
                     h->spike_m1 = m1;
                 } else {
-                    for (int w = 0; w < 2; ++w) { if (p64[w]) (void)hipFree(p64[w]); if (p32[w]) (void)hipFree(p32[w]); }
+                    for (int w = 0; w < 2; ++w) { if (p64[w]) dfree(p64[w]); if (p32[w]) dfree(p32[w]); }
                 }
             }
         }
@@ -1585,6 +1688,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(hipStreamSynchronize(st));
     }
     mark("interface descriptors");
+    if (trace) fprintf(stderr, "[spike setup] of which inside hipMalloc / hipFree: %.3f ms in %d calls\n", g_alloc_ms, g_alloc_n);
+    g_alloc_trace = false;
     if (multi && !h->dSend) {
         HIPCHK(dalloc(&h->dSend, (size_t)2 * (K > 0 ? K : 1)));
         HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * 2 * (K > 0 ? K : 1)));
@@ -1592,6 +1697,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     HIPCHK(hipStreamSynchronize(st));
     h->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     h->ready = true;
+    cache_flush(&h->cache, h->cache.gen);   // idle blocks this setup did not touch go back to the driver
     return SPIKE_OK;
 }
 
@@ -1749,7 +1855,7 @@ static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_
             // the diagonal-major copy has served its purpose (setup read the coupling blocks and tip right-hand sides
             // from it): the mat-vec streams the tile-major copy from now on -- 8.6 GB less resident at the headline size
             HIPCHK(hipStreamSynchronize(st));
-            (void)hipFree(h->dA);
+            dfree(h->dA);
             h->dA = nullptr; h->ownA = false;
         } else { h->dAt = nullptr; (void)hipGetLastError(); }  // no memory for the copy: stream the diagonal-major band
     }
@@ -1822,7 +1928,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
     // the multi-vector kernels are limited by how many pages a CU touches per trip, see spike_krylov.hip)
     const int64_t ldv = n;
     if (h->gm_restart != m || h->gm_ldv != ldv) {
-        auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+        auto F = [](auto *&p) { if (p) { dfree((void *)p); p = nullptr; } };
         F(h->dV); F(h->dW); F(h->dZ); F(h->dDots); F(h->dCoef); F(h->dRedWs);
         for (int i = 0; i < 2; ++i) {
             if (h->hostDots[i]) { (void)hipHostFree(h->hostDots[i]); h->hostDots[i] = nullptr; }
@@ -1960,9 +2066,9 @@ extern "C" int spike_clear_operator(spike_handle h)
 {
     if (!h) return SPIKE_ERR_ARG;
     (void)hipStreamSynchronize(h->stream);
-    if (h->op_ia) (void)hipFree(h->op_ia);
-    if (h->op_ja) (void)hipFree(h->op_ja);
-    if (h->op_a) (void)hipFree(h->op_a);
+    if (h->op_ia) dfree(h->op_ia);
+    if (h->op_ja) dfree(h->op_ja);
+    if (h->op_a) dfree(h->op_a);
     h->op_ia = nullptr; h->op_ja = nullptr; h->op_a = nullptr; h->op_n = h->op_nnz = 0;
     return SPIKE_OK;
 }
@@ -1999,7 +2105,7 @@ extern "C" int spike_set_operator_band(spike_handle h, const double *band_dev, i
     if (!h) return SPIKE_ERR_ARG;
     if (!band_dev) {  // clear
         (void)hipStreamSynchronize(h->stream);
-        if (h->dAtOp) { (void)hipFree(h->dAtOp); h->dAtOp = nullptr; }
+        if (h->dAtOp) { dfree(h->dAtOp); h->dAtOp = nullptr; }
         return SPIKE_OK;
     }
     if (!h->ready) return fail(h, SPIKE_ERR_STATE, "spike_set_operator_band needs a setup (it takes n and K from it)");

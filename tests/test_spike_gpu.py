@@ -511,3 +511,45 @@ def test_wavefront_scan_four_rows_per_lane(spike, oracle, torch_cuda, K):
                 assert _rel(so.apply(f), x) <= TOL, (N, P, vname, key)
                 so.close()
             sp.close()
+
+
+def test_workspace_is_recycled_between_setups(spike, oracle, torch_cuda):
+    """Refactorisation on one handle (the reference: PCSetUp(b->pc) on every call, matbanded.c:178): the handle's device blocks
+    are handed out again by size instead of going through hipFree / hipMalloc (option workspace_cache, default on).  Same
+    results as without recycling, bit for bit; a changed shape does not pile up memory; spike_reset gives everything back."""
+    torch = torch_cuda
+    N, K, P = 2 ** 16, 40, 8
+    f = oracle.gen_vec(N)
+    bands = [oracle.gen_band(N, K, seed=s) for s in (1, 2, 3)]
+    res = {}
+    for mode in ("on", "off"):
+        sp = spike.Spike(partitions=P)
+        sp.set_option("workspace_cache", mode)
+        out = []
+        for b in bands + [bands[0]]:
+            sp.setup_band(b)
+            out.append(sp.apply(f))
+        res[mode] = out
+        assert np.array_equal(out[0], out[3])                       # the same matrix again: the same bits
+        sp.close()
+    for a, b in zip(res["on"], res["off"]):
+        assert np.array_equal(a, b)
+    for b, x in zip(bands, res["on"]):
+        assert _rel(x, oracle.Spike(b, P).apply(f, 1)) <= TOL
+    # shapes that change from setup to setup: idle blocks of a shape no longer in use are released after one setup
+    sp = spike.Spike()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    held = []
+    for (n, k) in [(2 ** 18, 64), (2 ** 16, 8), (2 ** 18, 64), (2 ** 15, 128), (2 ** 15, 128), (2 ** 15, 128)]:
+        band = spike.gen_band_device(n, k, seed=5, delta=1.2)
+        sp.setup_band(band)
+        del band
+        torch.cuda.synchronize(); torch.cuda.empty_cache()           # (torch's cache of the generated band is not the library's)
+        held.append(free0 - torch.cuda.mem_get_info()[0])
+    assert held[-1] == held[-2]                                      # steady state: nothing grows
+    assert held[-1] < held[0]                                        # the large first shape did not stay behind
+    assert sp.L.spike_reset(sp.h) == 0
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 64 * 2 ** 20
+    sp.close()

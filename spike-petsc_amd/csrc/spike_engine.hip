@@ -1068,13 +1068,19 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     hipStream_t st = h->stream;
 
     // band on device (kept for the coupling blocks, the tips and the Krylov matvec)
+    bool fuse_copy = false;
     if (on_device && !h->keep_band) { h->dA = const_cast<double *>(band); h->ownA = false; h->ldA = ld; }
     else {
         HIPCHK(dalloc(&h->dA, (size_t)nd * n));
         h->ownA = true; h->ldA = n;
-        HIPCHK(hipMemcpy2DAsync(h->dA, n * sizeof(double), band, ld * sizeof(double), n * sizeof(double), nd,
-                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        if (K > 0) {
+        // K > 32, band on the device: the transposing pass into the block-band LU scratch reads every band entry anyway and
+        // writes the kept copy on its way (launch_band_to_blocks) -- one read of the band instead of two
+        fuse_copy = on_device && lu_blocks_doubles(n, K) != 0 && getenv("SPIKE_NO_FUSED_BAND_COPY") == nullptr;
+        if (!fuse_copy) {
+            HIPCHK(hipMemcpy2DAsync(h->dA, n * sizeof(double), band, ld * sizeof(double), n * sizeof(double), nd,
+                                    on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        }
+        if (K > 0 && !fuse_copy) {
             const int64_t tot = (int64_t)2 * K * nd;
             hipLaunchKernelGGL(k_zero_corners, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->dA, h->ldA, K, n_global, row0, n);
             HIPCHK(hipGetLastError());
@@ -1120,7 +1126,7 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     // pivot-boost threshold = boost_rel * max|diag| (max over all ranks)
     double *dScal = nullptr;
     HIPCHK(tmp.alloc(&dScal, 2));
-    HIPCHK(launch_absmax_diag(h->dA, h->ldA, K, n, dScal, st));
+    HIPCHK(launch_absmax_diag(fuse_copy ? band : h->dA, fuse_copy ? ld : h->ldA, K, n, dScal, st));   // (the diagonal has no out-of-range slots)
     if ((rc = coll_allreduce(h, dScal, 1, NCCL_MAX))) return rc;
     double dmax = 0.0;
     HIPCHK(hipMemcpyAsync(&dmax, dScal, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1132,7 +1138,8 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
     double *dLU = nullptr;
     const size_t lu_blk = lu_blocks_doubles(n, K);   // K > 32: block-band scratch (dense 16 x 16 tiles), made in one transposing pass
     HIPCHK(tmp.alloc(&dLU, lu_blk ? lu_blk : (size_t)nd * n));
-    if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, h->dA, h->ldA, dLU, st, dMoff, dMdir));
+    if (lu_blk && fuse_copy) HIPCHK(launch_band_to_blocks(n, K, band, ld, dLU, st, dMoff, dMdir, h->dA, h->ldA, n_global, row0));
+    else if (lu_blk) HIPCHK(launch_band_to_blocks(n, K, h->dA, h->ldA, dLU, st, dMoff, dMdir));
     else if (tw) HIPCHK(launch_band_flip(h->dA, h->ldA, K, h->dChains, P, h->max_chain_rows, dLU, n, st));   // the scratch copy IS the mirror
     else HIPCHK(hipMemcpy2DAsync(dLU, n * sizeof(double), h->dA, h->ldA * sizeof(double), n * sizeof(double), nd, hipMemcpyDeviceToDevice, st));
     unsigned long long *dNb = (unsigned long long *)(dScal + 1);

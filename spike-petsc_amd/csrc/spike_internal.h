@@ -100,8 +100,11 @@ hipError_t launch_sweep_multi(const SweepCfg &cfg, bool rev, int nchains, const 
 // made by launch_band_to_blocks from the diagonal-major band; lu_blocks_doubles = its size (0: diagonal-major scratch)
 size_t lu_blocks_doubles(int64_t n, int K);
 // moff / mdir (per 64-row block, or null): the twisted factorisation's row / diagonal mirror, applied while copying
+// copy != nullptr: the band entries are also written to copy (diagonal-major, row stride ldc) as they are read, with the slots
+// whose column lies outside [0, n_global) zeroed (in the copy and in the tiles): the library's kept copy of a caller's device band
 hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st,
-                                 const int64_t *moff = nullptr, const int *mdir = nullptr);
+                                 const int64_t *moff = nullptr, const int *mdir = nullptr, double *copy = nullptr, int64_t ldc = 0,
+                                 int64_t n_global = 0, int64_t row0 = 0);
 hipError_t launch_factor(double *lu, int64_t ld, int K, const ChainDesc *chains, int nchains, double boost,
                          unsigned long long *nboost, hipStream_t st);
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,

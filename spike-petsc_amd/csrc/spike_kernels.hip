@@ -1333,7 +1333,8 @@ __device__ __forceinline__ void lu_put(const LuView &v, int64_t rs, int r, int c
 // copy, which reads the band anyway
 template <int RB>
 __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB, const double *band, int64_t ld, double *T,
-                                                        const int64_t *moff, const int *mdir)
+                                                        const int64_t *moff, const int *mdir, double *copy, int64_t ldc,
+                                                        int64_t n_global, int64_t row0)
 {
     extern __shared__ double strip[];   // 16 RB x (W + 1), W = 16 * NTL + 16 (RB - 1)
     constexpr int RW = 16 * RB;
@@ -1358,6 +1359,20 @@ __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB
                 const int d = d0 + u * NSUB, dc = d < nd ? d : nd - 1;
                 v[u] = band[(int64_t)(mir ? nd - 1 - dc : dc) * ld + si];
             }
+            if (copy != nullptr) {
+                // the library's kept copy of the band is written on the way (this pass reads every band entry exactly once), slots
+                // whose column falls outside [0, n_global) zeroed as k_zero_corners does for the plain copy
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = d0 + u * NSUB;
+                    if (d < nd) {
+                        const int ds = mir ? nd - 1 - d : d;
+                        const int64_t c = row0 + si + ds - K;
+                        if (c < 0 || c >= n_global) v[u] = 0.0;
+                        copy[(int64_t)ds * ldc + si] = v[u];
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int d = d0 + u * NSUB;
@@ -1380,7 +1395,7 @@ __global__ __launch_bounds__(256) void k_band_to_blocks(int64_t n, int K, int KB
 static inline int lu_kb(int K) { return K <= 64 ? 4 : (K <= 128 ? 8 : 16); }
 
 hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t ld, double *T, hipStream_t st, const int64_t *moff,
-                                 const int *mdir)
+                                 const int *mdir, double *copy, int64_t ldc, int64_t n_global, int64_t row0)
 {
     if (n <= 0) return hipSuccess;
     const int KB = lu_kb(K), NTL = 2 * KB + 1;
@@ -1392,8 +1407,8 @@ hipError_t launch_band_to_blocks(int64_t n, int K, const double *band, int64_t l
         if (e != hipSuccess) return e;
     }
     const unsigned nwg = (unsigned)(((n + 15) / 16 + RB - 1) / RB);
-    if (RB == 2) hipLaunchKernelGGL(k_band_to_blocks<2>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir);
-    else hipLaunchKernelGGL(k_band_to_blocks<1>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir);
+    if (RB == 2) hipLaunchKernelGGL(k_band_to_blocks<2>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir, copy, ldc, n_global, row0);
+    else hipLaunchKernelGGL(k_band_to_blocks<1>, dim3(nwg), dim3(256), shm, st, n, K, KB, band, ld, T, moff, mdir, copy, ldc, n_global, row0);
     return hipGetLastError();
 }
 

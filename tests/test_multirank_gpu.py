@@ -40,7 +40,8 @@ def _split(N, G):
     return [(nblk * r // G) * 64 for r in range(G)] + [N]
 
 
-@pytest.mark.parametrize("G,N,K,Pl", [(2, 16384, 16, 4), (2, 32768, 128, 2), (4, 32768, 40, 2), (3, 24576, 8, 4), (2, 8192, 1, 2)])
+@pytest.mark.parametrize("G,N,K,Pl", [(2, 16384, 16, 4), (2, 32768, 128, 2), (4, 32768, 40, 2), (3, 24576, 8, 4), (2, 8192, 1, 2),
+                                      (2, 16384, 2, 4), (3, 24576 + 37, 3, 2)])   # (K <= 3: the wavefront scan across ranks)
 @pytest.mark.parametrize("variant", ["coupled", "decoupled"])
 def test_sharded_apply_equals_single_and_oracle(spike, oracle, G, N, K, Pl, variant):
     import torch
@@ -93,7 +94,7 @@ def test_unequal_row_blocks_take_the_same_collective_branches(spike, oracle, del
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
 
 
-@pytest.mark.parametrize("G,N,K", [(2, 65536, 16), (3, 98304, 40), (2, 131072, 128), (2, 32768, 1), (2, 65536, 4)])
+@pytest.mark.parametrize("G,N,K", [(2, 65536, 16), (3, 98304, 40), (2, 131072, 128), (2, 32768, 1), (2, 65536, 4), (2, 65536, 2), (3, 98304, 3)])
 def test_overlapped_exchange_is_bit_identical_and_exact(spike, oracle, G, N, K):
     """Several ranks: the tip exchange (all-gather), the rank-boundary interface solves and the corrections they drive
     run on a second stream while the local interface solves and corrections run on the main one (the

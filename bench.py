@@ -198,7 +198,6 @@ def main():
     K = args.k
     coupled = args.variant == "coupled"
 
-    warmed = [False]
 
     def measure(N, with_ksp, with_ceiling):
         """setup + the timed PCApply loop (+ KSP) on one system of N rows over all ranks"""
@@ -217,22 +216,10 @@ def main():
                 uid = torch.frombuffer(bytearray(S.unique_id()), dtype=torch.uint8).cuda()
             dist.broadcast(uid, 0)
             sp.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
-        if not warmed[0]:
-            # once per process: a setup of the same shape first, so that setup_s below does not contain the loading of the code
-            # object, the runtime's first-use costs (0.4-0.5 s on a fresh box) or its allocator's reaction to a first request of
-            # this size -- none of it setup work.  FULL local size since round 3: after a smaller warm-up (a quarter of the rows)
-            # the first hipMalloc of the timed setup stalled for 0.5-5 s on some boxes at K = 256 (17 GB buffers; three setups in a
-            # row WITHOUT a smaller one before them take 0.084 s each: tools/setup_repeat_k256.py)
-            wn = n_local
-            w = S.Spike(partitions=args.partitions, variant=args.variant)
-            w.set_option("subsplit", args.subsplit)
-            wband = S.gen_band_device(wn, K, seed=1, delta=args.delta)
-            w.setup_band(wband)
-            w.apply(torch.ones(wn, dtype=torch.float64, device="cuda"))
-            torch.cuda.synchronize()
-            w.close()
-            del wband
-            warmed[0] = True
+        # (Until round 3 a separate handle was set up and closed here to warm the process up.  Giving ~35 GB back to the driver
+        #  right before the timed handle allocates was measured to cost the APPLY 2-4 %: 1.373 / 1.413 / 1.414 ms per apply (median) with
+        #  it, 1.399 / 1.364 / 1.366 without, three processes each on one box -- the timed handle then lives in memory that was
+        #  just freed.  The handle's own first setup is the warm-up now; the timed setup is its second, as a refactorisation is.)
         band = S.gen_band_device(N, K, seed=12345, delta=args.delta, row0=r0, nrows=n_local)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -243,7 +230,8 @@ def main():
         setup_first_s = allmax(time.perf_counter() - t0)
         # the reference refactors on the same PC object (PCSetUp(b->pc) per call, matbanded.c:178): a second setup on this
         # handle, whose device blocks are recycled from the first one (engine option workspace_cache; a first setup's
-        # hipMalloc calls cost 5 ms on some boxes and a second at 8.6 GB on others -- the driver clears what it hands out)
+        # hipMalloc calls cost 5 ms on some boxes and a second at 8.6 GB on others -- the driver clears what it hands out).
+        # setup_first_s above also holds the process's first-use costs (code objects, 0.4-0.5 s on a fresh box).
         t0 = time.perf_counter()
         sp.setup_band(band, n_global=N, row0=r0)
         torch.cuda.synchronize()
@@ -372,8 +360,9 @@ def main():
             "max_abs_error_vs_exact_solution": m["err"],
             "setup_s": m["setup_s"], "setup_first_s": m["setup_first_s"],
             "setup_note": "setup_s = a refactorisation: the second setup on the handle (the reference calls PCSetUp on the same PC every "
-                          "time, matbanded.c:178), device blocks recycled from the first; setup_first_s = the handle's first setup, "
-                          "all its hipMalloc calls included (the driver clears what it hands out: 5 ms on some boxes, 1 s on others)",
+                          "time, matbanded.c:178), device blocks recycled from the first; setup_first_s = the handle's first setup: "
+                          "its hipMalloc calls (the driver clears what it hands out: 5 ms on some boxes, 1 s on others) and, in a fresh "
+                          "process, the loading of the code objects (0.4-0.5 s)",
             "ksp": m["ksp"],
             "roofline": {"bound": "hbm", "kernel": "k_sweep (forward+backward launch pair = one pass)",
                          "achieved": m["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",

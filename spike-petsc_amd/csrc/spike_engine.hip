@@ -1807,6 +1807,7 @@ extern "C" int spike_apply(spike_handle h, const double *x, double *y, int on_de
     if (on_device) return apply_dev(h, x, y);
     // host vectors: staged through two device buffers that live as long as the factors (a Krylov method calls this
     // once per iteration; PCIe moves 2*n*8 bytes per call)
+    CacheScope cache_scope(&h->cache);   // (buffers made on first use are recycled across refactorisations like the factors)
     if (!h->dStageX) HIPCHK(dalloc(&h->dStageX, (size_t)h->n));
     if (!h->dStageY) HIPCHK(dalloc(&h->dStageY, (size_t)h->n));
     HIPCHK(hipMemcpyAsync(h->dStageX, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
@@ -1842,6 +1843,7 @@ static int matvec_dev(spike_handle h, const double *x, double *y, double *scale_
         return SPIKE_OK;
     }
     const int K = h->K;
+    CacheScope cache_scope(&h->cache);   // dXh and the tile-major band copy: made on first use, recycled across refactorisations
     if (!h->dXh) HIPCHK(dalloc(&h->dXh, (size_t)h->n + 2 * (size_t)K));
     const bool multi = exchanging(h);
     if (multi && K > 0) {
@@ -1942,6 +1944,7 @@ extern "C" int spike_gmres(spike_handle h, const double *b, double *x, int resta
             HIPCHK(hipHostMalloc((void **)&h->hostDots[i], sizeof(double) * ((size_t)m + 3), hipHostMallocDefault));
             if (!h->evDots[i]) HIPCHK(hipEventCreateWithFlags(&h->evDots[i], hipEventDisableTiming));
         }
+        CacheScope cache_scope(&h->cache);   // the Krylov basis: recycled across refactorisations
         HIPCHK(dalloc(&h->dRedWs, red_workspace_doubles()));
         HIPCHK(hipMemsetAsync(h->dRedWs, 0, sizeof(double) * red_workspace_doubles(), st));
         HIPCHK(dalloc(&h->dV, (size_t)(m + 1) * ldv));

@@ -3382,11 +3382,21 @@ __global__ __launch_bounds__(1024) void k_iface_setup_lds(int K, const double *W
 static hipError_t iface_setup_blocked(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                                       double *work, int *flag, hipStream_t st);
 
+// smallest K that goes through 2 x 2 blocks (iface_setup_blocked): measurement knob SPIKE_IFACE_BLOCKED_KMIN, default 129
+static int iface_blocked_kmin()
+{
+    const char *e = getenv("SPIKE_IFACE_BLOCKED_KMIN");
+    const int v = e ? atoi(e) : 129;
+    return v < 34 ? 34 : v;
+}
+#define IFACE_BLOCKED_KMIN iface_blocked_kmin()
+
 hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, double *WT, double *VT, double *ST,
                               double *work, int *flag, hipStream_t st)
 {
     if (nif <= 0 || K <= 0) return hipSuccess;
-    if (K <= 128) {
+    const bool blocked = work != nullptr && K >= IFACE_BLOCKED_KMIN && K <= 256 && getenv("SPIKE_IFACE_UNBLOCKED") == nullptr;
+    if (K <= 128 && !blocked) {
         const int nt = K <= 8 ? 64 : (K <= 32 ? 256 : 1024);
         const size_t lds = ((size_t)K * (K + 1) + 2 * K + 16) * sizeof(double) + (16 + 2 * (size_t)K) * sizeof(int);
         // beyond 48 KiB the kernel needs its dynamic-LDS limit raised (cheap, so simply every time: no process-global state)
@@ -3398,7 +3408,7 @@ hipError_t launch_iface_setup(int K, int nif, const double *W, const double *V, 
             return hipGetLastError();
         }
     }
-    if (work != nullptr && K > 128 && K <= 256 && getenv("SPIKE_IFACE_UNBLOCKED") == nullptr) {
+    if (blocked) {
         // 2 x 2 blocks through the LDS kernel (the work area holds iface_setup_work_doubles); a zero pivot inside a diagonal block
         // or a failed verification of any system sends the whole batch to the unblocked kernel below
         hipError_t e = iface_setup_blocked(K, nif, W, V, WT, VT, ST, work, flag, st);
@@ -3517,7 +3527,7 @@ __global__ void k_check_identity(int K, const double *R, double tol, int *flag)
 size_t iface_setup_work_doubles(int K, int nif)
 {
     const size_t kk = (size_t)K * K;
-    if (K <= 128 || K > 256) return (size_t)nif * 2 * kk;   // the unblocked kernels: K (K + 1) per interface
+    if (K < IFACE_BLOCKED_KMIN || K > 256) return (size_t)nif * 2 * kk;   // the unblocked kernels: K (K + 1) per interface
     return (size_t)nif * 7 * kk;                             // S, S^-1, R + the half-size pieces (12 x <= kk/4 ... rounded up)
 }
 

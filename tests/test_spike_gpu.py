@@ -502,6 +502,15 @@ def test_wavefront_scan_four_rows_per_lane(spike, oracle, torch_cuda, K):
             sp.apply(fb[1:], xb[1:])
             torch.cuda.synchronize()
             assert np.array_equal(xb[1:].cpu().numpy(), x), (N, P, vname, "alignment variant differs")
+            # the two-pass form of the coupled variant (no stored spikes: the corrections enter the scan kernel's right-hand side)
+            if variant == 1:
+                s2 = spike.Spike(partitions=P, variant=vname)
+                s2.set_option("subsplit", sub); s2.set_option("spike_storage", "off")
+                s2.setup_band(band)
+                i2 = s2.info()
+                assert i2.spike_rows == 0 and i2.passes == (2 if i2.chains_local > 1 else 1)
+                assert _rel(s2.apply(f), x) <= TOL, (N, P, "two passes")
+                s2.close()
             # the paths it replaces
             alts = [("narrow_scan_kmax", 1)] if K > 1 else [("narrow_scan_rows", 1)]
             for key, val in alts:

@@ -2365,7 +2365,17 @@ __global__ __launch_bounds__(64) void k_pack(int DPW, int NW, const double *lu, 
 // (A variant with the inverse's column in 64 registers and a fully unrolled substitution was tried: the 2016 independent
 //  multiplier reads get hoisted above the serial FMA chain and spill ~7000 registers; measured 107 ms.)
 // ------------------------------------------------------------------------------------------
-constexpr int PACK_LDM = 65;   // LDS row stride of the 64 x 64 block in k_pack64
+// The 64 x 64 triangular block of k_pack64 in LDS: only its ten 16 x 16 tiles on and below the block diagonal, tile (tr, tc)
+// at slot tr (tr + 1) / 2 + tc, rows of a tile 17 doubles apart (conflict-free by rows and by columns): 21.3 KiB instead of
+// the 32.5 KiB of a padded square -- with the 16.1 KiB strip that is FOUR one-wave workgroups per CU instead of three, and
+// the kernel's time goes with its occupancy (measured by giving it unused LDS: 1 / 2 / 3 workgroups per CU 10.9 / 5.7 / 4.0 ms).
+constexpr int PACK_TS = 16 * 17;            // doubles per tile
+constexpr int PACK_MS = 10 * PACK_TS;       // doubles of the block
+__device__ __forceinline__ int pack_ms(int r, int c)   // element (r, c), c's tile column <= r's tile row
+{
+    const int tr = r >> 4, tc = c >> 4;
+    return ((tr * (tr + 1)) / 2 + tc) * PACK_TS + (r & 15) * 17 + (c & 15);
+}
 
 // In-place inverse of a 64 x 64 UNIT LOWER triangular matrix held row-major in LDS (only the strictly lower triangle is
 // read and written; the unit diagonal is implicit), by ONE wave:
@@ -2379,37 +2389,36 @@ constexpr int PACK_LDM = 65;   // LDS row stride of the 64 x 64 block in k_pack6
 // k_pack64); this is 64 MFMAs plus 120 serial multiply-adds.
 __device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
 {
-    constexpr int R = PACK_LDM;   // row stride of Ms (padded: a stride of 64 doubles puts a whole column into one LDS bank)
     typedef double v4 __attribute__((ext_vector_type(4)));
     const int li = lane & 15, lk = lane >> 4;
     // ---- A: diagonal tiles
     {
         const int tile = lk, j = li;
-        const double *D = Ms + (16 * tile) * R + 16 * tile;
+        const double *D = Ms + pack_ms(16 * tile, 16 * tile);   // diagonal tile: element (q, c) at D[q * 17 + c]
         double xc[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             double acc = (q == j) ? 1.0 : 0.0;
 #pragma unroll
-            for (int c = 0; c < q; ++c) acc = fma(-D[q * R + c], xc[c], acc);
+            for (int c = 0; c < q; ++c) acc = fma(-D[q * 17 + c], xc[c], acc);
             xc[q] = acc;
         }
         WAVE_LDS_FENCE();
 #pragma unroll
         for (int q = 1; q < 16; ++q)
-            if (q > j) Ms[(16 * tile + q) * R + 16 * tile + j] = xc[q];
+            if (q > j) Ms[pack_ms(16 * tile + q, 16 * tile + j)] = xc[q];
         WAVE_LDS_FENCE();
     }
     // operand loaders.  A-layout: lane holds A[i = l&15][k = 4q + (l>>4)]; B-layout: B[k = 4q + (l>>4)][j = l&15]
     auto loadA_full = [&](int ti, int tk, double(&a)[4]) {     // off-diagonal tile (ti > tk) of M
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = Ms[(16 * ti + li) * R + 16 * tk + 4 * q + lk];
+        for (int q = 0; q < 4; ++q) a[q] = Ms[pack_ms(16 * ti + li, 16 * tk + 4 * q + lk)];
     };
     auto loadA_diag = [&](int t, double(&a)[4]) {              // E_t: unit lower, stored strictly lower
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 4 * q + lk;
-            const double v = Ms[(16 * t + li) * R + 16 * t + (k < li ? k : 0)];
+            const double v = Ms[pack_ms(16 * t + li, 16 * t + (k < li ? k : 0))];
             a[q] = k < li ? v : (k == li ? 1.0 : 0.0);
         }
     };
@@ -2417,7 +2426,7 @@ __device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 4 * q + lk;                          // row of E_t, column li
-            const double v = Ms[(16 * t + (k > li ? k : 15)) * R + 16 * t + (k > li ? li : 0)];
+            const double v = Ms[pack_ms(16 * t + (k > li ? k : 15), 16 * t + (k > li ? li : 0))];
             b[q] = k > li ? v : (k == li ? 1.0 : 0.0);
         }
     };
@@ -2457,7 +2466,7 @@ __device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
 #pragma unroll
         for (int j = 0; j < i; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ms[(16 * i + lk + 4 * r) * R + 16 * j + li] = X[i][j][r];
+            for (int r = 0; r < 4; ++r) Ms[pack_ms(16 * i + lk + 4 * r, 16 * j + li)] = X[i][j][r];
     WAVE_LDS_FENCE();
 }
 
@@ -2500,10 +2509,10 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
             for (int e = 0; e < 2; ++e) {
                 const int cc = 2 * q + e;                          // block column of this entry
                 const double v = e == 0 ? rv[q].x : rv[q].y;
-                if (!UPPER) Ms[lane * PACK_LDM + cc] = (rowok && cc < lane) ? v : 0.0;
+                if (!UPPER) { if ((cc >> 4) <= (lane >> 4)) Ms[pack_ms(lane, cc)] = (rowok && cc < lane) ? v : 0.0; }
                 else {                                             // flipped: slot (lane, 63 - cc) <- U[r][cc] * di, cc > r
                     const bool use = rowok && cc > r && cc < rows_here;
-                    Ms[lane * PACK_LDM + (R - 1 - cc)] = use ? v * di : 0.0;
+                    if (((R - 1 - cc) >> 4) <= (lane >> 4)) Ms[pack_ms(lane, R - 1 - cc)] = use ? v * di : 0.0;
                 }
             }
         }
@@ -2582,7 +2591,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
         const bool rok = rin < rows_here;
         const double dsc = UPPER ? dis[rin] : 1.0;
         auto entry = [&](int d) -> double {
-            if (d <= L) return -Ms[L * PACK_LDM + (L - d)];
+            if (d <= L) return -Ms[pack_ms(L, L - d)];
             const bool far_ok = d <= K && rok && (UPPER ? (rloc + d < cd.nrows) : (rloc - d >= 0));
             const int c = UPPER ? rloc + d : rloc - d;         // chain-local column
             const int fc = far_ok ? c - 16 * cbf : 0;          // column inside the strip
@@ -2607,7 +2616,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
 __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, LuView lv, int K, const ChainDesc *chains,
                                                const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
 {
-    __shared__ double Ms[64 * PACK_LDM];
+    __shared__ double Ms[PACK_MS];
     __shared__ double dis[64];
     extern __shared__ double Fs[];   // 16 x (16 ceil(K/16) + 1): the strip of far tiles
     const int sb = blockIdx.x, p = blockIdx.y;
@@ -2639,7 +2648,12 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
         }
         LuView lv;   // K > 32: the scratch is block-band (launch_band_to_blocks / launch_factor)
         lv.p = const_cast<double *>(lu); lv.ld = ld; lv.K = K; lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;
-        hipLaunchKernelGGL(k_pack64, grid, dim3(64), (size_t)16 * (16 * ((K + 15) / 16) + 1) * sizeof(double), st, cfg.DPW, cfg.NW, lv, K,
+        size_t extra_lds = 0;
+        if (const char *e = getenv("SPIKE_PACK_EXTRA_LDS_KB")) {   // occupancy experiment: unused LDS (fewer workgroups per CU)
+            extra_lds = (size_t)atoi(e) * 1024;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pack64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(extra_lds + 20000));
+        }
+        hipLaunchKernelGGL(k_pack64, grid, dim3(64), (size_t)16 * (16 * ((K + 15) / 16) + 1) * sizeof(double) + extra_lds, st, cfg.DPW, cfg.NW, lv, K,
                            chains, groups, Lt, Ut, dinv);
         break;
     }

@@ -2470,7 +2470,8 @@ __device__ __forceinline__ void invert_unit_lower_64(double *Ms, int lane)
     WAVE_LDS_FENCE();
 }
 
-template <bool UPPER>
+// SR = rows of the far-tile strip held in LDS at a time: 16 (a whole tile strip) or 8 (half of one)
+template <bool UPPER, int SR>
 __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis, int DPW, int NW, const LuView &lv, int K,
                                             const ChainDesc &cd, int sb, double *T, double *dinv)
 {
@@ -2529,7 +2530,12 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
     (void)DPW;
     const int KBv = (K + 15) >> 4;                             // far tiles per strip, at most
     const int FS = 16 * KBv + 1;                               // strip row stride (odd: FS + 1 = 2 mod 16 -> no bank conflicts)
-    const int row16 = lane & 15, q = lane >> 4;
+    // SR = 8 (K > 128): the strip in LDS holds half of a 16-row tile strip, 16 KiB at K = 256 -- four workgroups per CU instead
+    // of two: 10.2 -> 6.3 ms at K = 256.  At K <= 128 the whole strip leaves room for four workgroups already and half strips
+    // were measured slightly slower (3.45 -> 3.57 ms: half the prefetch distance, 128-byte instead of 256-byte store runs).
+    constexpr int NH = 16 / SR;                               // strip pieces per tile strip
+    constexpr int QN = 64 / SR;                               // slot groups among the lanes
+    const int rowS = lane % SR, q = lane / SR;
     const int nblk16 = (cd.nrows + 15) >> 4;
     d2 *T2 = reinterpret_cast<d2 *>(T);
     const int nslots = 16 * NW;
@@ -2559,7 +2565,7 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
             }
         }
     };
-    auto store_strip = [&](int rbl) {
+    auto store_strip = [&](int rbl, int hh) {                  // SR = 8: rows 8 hh .. 8 hh + 7 of the strip's tiles = the lanes' piece hh
         int rb, ntf, cbf;
         strip_of(rbl, rb, ntf, cbf);
 #pragma unroll
@@ -2569,11 +2575,17 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = 8 * ch + jj;
                 if (j >= ntf) continue;
+                // pair index inside the tile: lane + 64 piece = row (lane >> 3) + 8 piece, columns 2 (lane & 7), +1
+                if (SR == 8) {
+                    double *dst = Fs + (lane >> 3) * FS + 16 * j + 2 * (lane & 7);
+                    const d2 t = hh == 0 ? tv[ch][2 * jj] : tv[ch][2 * jj + 1];
+                    dst[0] = t.x; dst[1] = t.y;
+                } else {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int e2 = lane + 64 * hh;             // pair index inside the tile: row e2 >> 3, columns 2 (e2 & 7), +1
-                    double *dst = Fs + (e2 >> 3) * FS + 16 * j + 2 * (e2 & 7);
-                    dst[0] = tv[ch][2 * jj + hh].x; dst[1] = tv[ch][2 * jj + hh].y;
+                    for (int pc = 0; pc < 2; ++pc) {
+                        double *dst = Fs + ((lane >> 3) + 8 * pc) * FS + 16 * j + 2 * (lane & 7);
+                        dst[0] = tv[ch][2 * jj + pc].x; dst[1] = tv[ch][2 * jj + pc].y;
+                    }
                 }
             }
         }
@@ -2582,51 +2594,55 @@ __device__ __forceinline__ void pack64_side(double *Ms, double *Fs, double *dis,
     for (int rbl = 0; rbl < 4; ++rbl) {
         int rb, ntf, cbf;
         strip_of(rbl, rb, ntf, cbf);
-        store_strip(rbl);
-        WAVE_LDS_FENCE();
-        if (rbl < 3) issue_strip(rbl + 1);
-        const int rin = 16 * rbl + row16;                      // row of the block (storage order)
-        const int L = UPPER ? R - 1 - rin : rin;               // its tile lane
-        const int rloc = sb * R + rin;                         // chain-local row
-        const bool rok = rin < rows_here;
-        const double dsc = UPPER ? dis[rin] : 1.0;
-        auto entry = [&](int d) -> double {
-            if (d <= L) return -Ms[pack_ms(L, L - d)];
-            const bool far_ok = d <= K && rok && (UPPER ? (rloc + d < cd.nrows) : (rloc - d >= 0));
-            const int c = UPPER ? rloc + d : rloc - d;         // chain-local column
-            const int fc = far_ok ? c - 16 * cbf : 0;          // column inside the strip
-            const double g = Fs[row16 * FS + fc];
-            return far_ok ? g * dsc : 0.0;
-        };
-        for (int s0 = 0; s0 < nslots; s0 += 16) {
-            d2 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int slot = s0 + 4 * u + q;
-                v[u].x = entry(2 * slot + 1);
-                v[u].y = entry(2 * slot + 2);
+        for (int hh = 0; hh < NH; ++hh) {
+            store_strip(rbl, hh);
+            WAVE_LDS_FENCE();
+            if (hh == NH - 1 && rbl < 3) issue_strip(rbl + 1);  // (the registers of this strip's tiles are free from here on)
+            const int rin = 16 * rbl + SR * hh + rowS;             // row of the block (storage order)
+            const int L = UPPER ? R - 1 - rin : rin;               // its tile lane
+            const int rloc = sb * R + rin;                         // chain-local row
+            const bool rok = rin < rows_here;
+            const double dsc = UPPER ? dis[rin] : 1.0;
+            auto entry = [&](int d) -> double {
+                if (d <= L) return -Ms[pack_ms(L, L - d)];
+                const bool far_ok = d <= K && rok && (UPPER ? (rloc + d < cd.nrows) : (rloc - d >= 0));
+                const int c = UPPER ? rloc + d : rloc - d;         // chain-local column
+                const int fc = far_ok ? c - 16 * cbf : 0;          // column inside the strip
+                const double g = Fs[rowS * FS + fc];
+                return far_ok ? g * dsc : 0.0;
+            };
+            for (int s0 = 0; s0 < nslots; s0 += 16) {
+                d2 v[16 / QN];
+#pragma unroll
+                for (int u = 0; u < 16 / QN; ++u) {
+                    const int slot = s0 + QN * u + q;
+                    v[u].x = entry(2 * slot + 1);
+                    v[u].y = entry(2 * slot + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 16 / QN; ++u) T2[(int64_t)(s0 + QN * u + q) * 64 + L] = v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) T2[(int64_t)(s0 + 4 * u + q) * 64 + L] = v[u];
+            WAVE_LDS_FENCE();                                      // the strip is overwritten by the next half
         }
-        WAVE_LDS_FENCE();                                      // the strip is overwritten by the next one
     }
 }
 
+template <int SR>
 __global__ __launch_bounds__(64) void k_pack64(int DPW, int NW, LuView lv, int K, const ChainDesc *chains,
                                                const GroupDesc *groups, double *Lt, double *Ut, double *dinv)
 {
     __shared__ double Ms[PACK_MS];
     __shared__ double dis[64];
-    extern __shared__ double Fs[];   // 16 x (16 ceil(K/16) + 1): the strip of far tiles
+    extern __shared__ double Fs[];   // SR x (16 ceil(K/16) + 1): the strip of far tiles (SR = 8: half of it at a time)
     const int sb = blockIdx.x, p = blockIdx.y;
     const ChainDesc cd = chains[p];
     if (sb >= cd.nsteps) return;
     const GroupDesc gd = groups[p];
     const int64_t tdbl = (int64_t)NW * DPW * 64;
-    pack64_side<false>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
+    pack64_side<false, SR>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Lt + (gd.tile0 + sb) * tdbl, dinv);
     WAVE_LDS_FENCE();
-    pack64_side<true>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
+    pack64_side<true, SR>(Ms, Fs, dis, DPW, NW, lv, K, cd, sb, Ut + (gd.tile0 + (cd.nsteps - 1 - sb)) * tdbl, dinv);
 }
 
 hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K, const ChainDesc *chains,
@@ -2648,13 +2664,11 @@ hipError_t launch_pack(const SweepCfg &cfg, const double *lu, int64_t ld, int K,
         }
         LuView lv;   // K > 32: the scratch is block-band (launch_band_to_blocks / launch_factor)
         lv.p = const_cast<double *>(lu); lv.ld = ld; lv.K = K; lv.KB = lu_kb(K); lv.ntl = 2 * lv.KB + 1;
-        size_t extra_lds = 0;
-        if (const char *e = getenv("SPIKE_PACK_EXTRA_LDS_KB")) {   // occupancy experiment: unused LDS (fewer workgroups per CU)
-            extra_lds = (size_t)atoi(e) * 1024;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pack64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(extra_lds + 20000));
-        }
-        hipLaunchKernelGGL(k_pack64, grid, dim3(64), (size_t)16 * (16 * ((K + 15) / 16) + 1) * sizeof(double) + extra_lds, st, cfg.DPW, cfg.NW, lv, K,
-                           chains, groups, Lt, Ut, dinv);
+        // (the occupancy experiment behind the LDS layout -- the same kernel handed 28 / 60 KiB of unused LDS, i.e. 2 / 1 workgroups
+        //  per CU instead of 3: 5.7 / 10.9 ms against 4.0 -- is recorded in DESIGN.md section 4)
+        const size_t fs_row = (size_t)(16 * ((K + 15) / 16) + 1) * sizeof(double);
+        if (K > 128) hipLaunchKernelGGL((k_pack64<8>), grid, dim3(64), 8 * fs_row, st, cfg.DPW, cfg.NW, lv, K, chains, groups, Lt, Ut, dinv);
+        else hipLaunchKernelGGL((k_pack64<16>), grid, dim3(64), 16 * fs_row, st, cfg.DPW, cfg.NW, lv, K, chains, groups, Lt, Ut, dinv);
         break;
     }
     default: return hipErrorInvalidValue;

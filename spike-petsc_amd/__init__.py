@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__)) if "__file__" in globals() else os.getcwd()
 if os.path.basename(_HERE) == "spike_petsc_amd":  # executed through the import shim
     _HERE = os.path.join(os.path.dirname(_HERE), "spike-petsc_amd")
-LIB_PATH = os.path.join(_HERE, "libspike_mi355.so")
+LIB_PATH = os.environ.get("SPIKE_MI355_LIB") or os.path.join(_HERE, "libspike_mi355.so")   # (override: A/B of two builds)
 
 i64 = C.c_int64
 dptr = C.POINTER(C.c_double)

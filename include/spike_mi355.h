@@ -110,6 +110,10 @@ const char *spike_last_error(spike_handle h);
  *       "correct_threads" (64|128|256: workgroup size of the spike correction, measurement option),
  *       "narrow_scan_kmax" (1..3, default 3: half-bandwidths up to this are solved by the wavefront scan -- no tiles, the
  *        algorithmic (2K+3)*8 bytes per row -- above it by the tile sweeps; same preconditioner),
+ *       "sweep_autotune" ("on"|"off", default on: K > 64 with chains of >= 8192 rows: the first setup of a shape on a handle times
+ *        the candidate sweep shapes (how the diagonals of a chain are dealt to waves, bundles in flight) over the real factors,
+ *        ~12 ms once, and keeps the fastest -- which one that is depends on the device; off: the base shape.  Same
+ *        preconditioner; the cross-wave summation order, hence the last bits, may differ between two choices),
  *       "workspace_cache" ("on"|"off", default on: the device blocks of a handle are recycled by size between its setups --
  *        a refactorisation on the same handle makes no hipMalloc / hipFree calls; idle blocks a whole setup did not use are
  *        released at its end, spike_reset / spike_destroy release everything; off: every setup allocates and frees),

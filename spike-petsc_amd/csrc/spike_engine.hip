@@ -208,6 +208,10 @@ struct spike_handle_s {
     int nif_local_all = 0;                                // interfaces between this rank's chains
     int scan_kmax = DEFAULT_SCAN_KMAX, scan_rows = DEFAULT_SCAN_ROWS;   // wavefront scan for K <= scan_kmax (options narrow_scan_kmax / narrow_scan_rows)
     int64_t scan_lds = 0;                                 // row stride of the k_nscan_* coefficient arrays
+    int sweep_tune = 1;                                   // option sweep_autotune: time the candidate sweep shapes at setup (K > 64, long chains)
+    int tuned_sig_K = -1; int64_t tuned_sig_n = -1; int tuned_sig_P = -1, tuned_sig_tw = -1;   // what the kept choice was measured for
+    int tuned_dpw = 0, tuned_nw = 0, tuned_pf = 0;
+    double tuned_ms[3] = {0, 0, 0};
     DevCache cache;                                       // device blocks recycled between setups (option workspace_cache)
     int small_kmax = 3;                                   // one-launch coupling step for K <= this (option small_coupling_kmax; K = 2, 3: behind the fused scan only; the generic K <= 8 kernel gains nothing)
     double *dStageX = nullptr, *dStageY = nullptr;        // staging for host-pointer applies
@@ -551,6 +555,7 @@ extern "C" int spike_set_option(spike_handle h, const char *key, const char *val
         else return fail(h, SPIKE_ERR_ARG, "iface_form is 'matrix' or 'staged'");
     }
     else if (k == "overlap_exchange") h->overlap = (v == "off" || v == "0") ? 0 : 1;
+    else if (k == "sweep_autotune") { h->sweep_tune = !(v == "off" || v == "0"); h->tuned_sig_K = -1; }
     else if (k == "workspace_cache") {
         h->cache.enabled = !(v == "off" || v == "0");
         if (!h->cache.enabled) cache_flush(&h->cache, INT_MAX);
@@ -813,13 +818,15 @@ static int build_chains(spike_handle h)
     const int ng = (P + CPW - 1) / CPW;
     h->groups.resize(ng);
     int64_t t0 = 0, ms = 0;
+    int tile_pad = 0;   // unused tiles between the groups' tile runs (measurement knob: skews the chains' streams against each other)
+    if (const char *e = getenv("SPIKE_TILE_PAD")) tile_pad = atoi(e) > 0 ? atoi(e) : 0;
     for (int q = 0; q < ng; ++q) {
         int mx = 0;
         for (int c = 0; c < CPW && q * CPW + c < P; ++c) mx = std::max(mx, (int)h->chains[q * CPW + c].nsteps);
         h->groups[q].tile0 = t0;
         h->groups[q].maxsteps = mx;
         h->groups[q].pad = 0;
-        t0 += mx;
+        t0 += mx + tile_pad;
         ms = std::max<int64_t>(ms, mx);
     }
     h->ntiles = t0;
@@ -1702,6 +1709,57 @@ static int setup_impl(spike_handle h, int64_t n_global, int64_t row0, int64_t n,
         HIPCHK(dalloc(&h->dRecv, (size_t)h->nranks * 2 * (K > 0 ? K : 1)));
     }
     HIPCHK(hipStreamSynchronize(st));
+    // ---- sweep shape by measurement (K > 64, chains of >= 8192 rows, the first setup of a shape on this handle).  How the KP
+    // diagonals of a chain are dealt to waves (32 per wave x NW waves, or 16 x 2 NW) and how many bundles a wave keeps in
+    // flight changes nothing in the bytes moved, but which of them is faster depends on the device in a way no rule caught:
+    // at the headline size 32 x 4 with two bundles reads 1.38-1.43 ms per apply by box, 16 x 8 reads 1.325 on some boxes
+    // (-4 ... -7 %) and 1.41-1.47 on others (profiles/r3_sweep_shapes.log).  Three timed passes per candidate over the real
+    // factors (zero right-hand side), about 12 ms once; a refactorisation keeps the choice.  The candidates differ in the
+    // order of their cross-wave sums, i.e. results may differ in the last bits between two runs that chose differently:
+    // option sweep_autotune = off (or the SPIKE_SWEEP_SHAPE knob) pins the base shape.
+    if (h->sweep_tune && cfg.R == 64 && !cfg.scan && cfg.NW >= 3 && K <= 256 && h->min_chain_rows >= 8192 && getenv("SPIKE_SWEEP_SHAPE") == nullptr) {
+        const bool same = h->tuned_sig_K == K && h->tuned_sig_n == n && h->tuned_sig_P == P && h->tuned_sig_tw == (int)h->twisted;
+        if (!same) {
+            struct Cand { int d, w, f; };
+            std::vector<Cand> cands;
+            cands.push_back({0, 0, 0});   // the base shape
+            if (sweep_shape_exists(h->cfg, 16, 2 * cfg.NW, 2)) cands.push_back({16, 2 * cfg.NW, 2});
+            if (sweep_shape_exists(h->cfg, cfg.DPW, cfg.NW, 4)) cands.push_back({cfg.DPW, cfg.NW, 4});
+            double *tin = nullptr, *tout = nullptr;
+            HIPCHK(tmp.alloc(&tin, (size_t)n));
+            HIPCHK(tmp.alloc(&tout, (size_t)n));
+            HIPCHK(hipMemsetAsync(tin, 0, sizeof(double) * n, st));
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            h->ready = true;   // (run_pass then takes the PCApply chains and kernels)
+            int best = 0;
+            double best_ms = 1e300;
+            for (size_t ci = 0; ci < cands.size() && ci < 3; ++ci) {
+                h->cfg.sDPW = cands[ci].d; h->cfg.sNW = cands[ci].w; h->cfg.sPF = cands[ci].f;
+                int rc2 = run_pass(h, tin, tout, false);   // warm
+                double ms_min = 1e300;
+                for (int rep = 0; rep < 3 && rc2 == SPIKE_OK; ++rep) {
+                    (void)hipEventRecord(e0, st);
+                    rc2 = run_pass(h, tin, tout, false);
+                    (void)hipEventRecord(e1, st);
+                    (void)hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < ms_min) ms_min = ms;
+                }
+                if (rc2 != SPIKE_OK) { h->ready = false; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc2; }
+                h->tuned_ms[ci] = ms_min;
+                if (ms_min < best_ms * 0.995) { best_ms = ms_min; best = (int)ci; }   // a later candidate must win by 0.5 %
+            }
+            h->ready = false;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            h->tuned_dpw = cands[best].d; h->tuned_nw = cands[best].w; h->tuned_pf = cands[best].f;
+            h->tuned_sig_K = K; h->tuned_sig_n = n; h->tuned_sig_P = P; h->tuned_sig_tw = (int)h->twisted;
+            tmp.release(tin); tmp.release(tout);
+            mark("sweep shape timing");
+        }
+        h->cfg.sDPW = h->tuned_dpw; h->cfg.sNW = h->tuned_nw; h->cfg.sPF = h->tuned_pf;
+    }
     h->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     h->ready = true;
     cache_flush(&h->cache, h->cache.gen);   // idle blocks this setup did not touch go back to the driver
@@ -2275,6 +2333,13 @@ extern "C" int spike_view(spike_handle h, char *buf, size_t len)
              h->variant == SPIKE_VARIANT_COUPLED ? "coupled (truncated)" : "decoupled", h->cfg.nscan ? NSCAN_ROWS_PER_BLOCK : h->cfg.R, h->cfg.NW,
              (long long)h->nboost, h->setup_ms, h->nranks, h->spike_m, h->spike_m1, h->P,
              h->twisted ? " (twisted pairs)" : h->cfg.nscan ? " (wavefront scan, 4 rows per lane)" : h->cfg.scan ? " (wavefront scan)" : "");
+    if (h->tuned_sig_K == h->K && h->tuned_sig_n == h->n && h->ready) {   // the sweep shape was chosen by timing (setup_impl)
+        const size_t L0 = strlen(buf);
+        if (L0 + 1 < len)
+            snprintf(buf + L0, len - L0, "    sweep shape = %d diagonals x %d waves, %d bundles in flight (timed passes: base %.4f, 16-diagonal waves %.4f, 4 bundles %.4f ms)\n",
+                     h->cfg.sDPW ? h->cfg.sDPW : h->cfg.DPW, h->cfg.sNW ? h->cfg.sNW : h->cfg.NW, h->cfg.sPF ? h->cfg.sPF : h->cfg.basePF(),
+                     h->tuned_ms[0], h->tuned_ms[1], h->tuned_ms[2]);
+    }
     return SPIKE_OK;
 }
 

@@ -562,3 +562,46 @@ def test_workspace_is_recycled_between_setups(spike, oracle, torch_cuda):
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     assert free0 - torch.cuda.mem_get_info()[0] <= 64 * 2 ** 20
     sp.close()
+
+
+@pytest.mark.parametrize("K,shape", [(96, "16,6,2"), (96, "16,6,4"), (128, "16,8,2"), (128, "32,4,4"), (128, "16,8,4"), (200, "16,16,2"), (256, "16,16,2")])
+def test_sweep_shapes_match_oracle(spike, oracle, torch_cuda, K, shape):
+    """The shapes the setup-time measurement may choose between (diagonals per wave x waves x bundles in flight; measurement
+    knob SPIKE_SWEEP_SHAPE pins one): same preconditioner as the oracle's, whichever shape sweeps."""
+    import os
+    N, P = 2 ** 15, 4
+    band = oracle.gen_band(N, K, delta=1.1)
+    f = oracle.gen_vec(N)
+    xo = oracle.Spike(band, P).apply(f, 1)
+    os.environ["SPIKE_SWEEP_SHAPE"] = shape
+    try:
+        sp = spike.Spike(partitions=P).setup_band(band)
+    finally:
+        os.environ.pop("SPIKE_SWEEP_SHAPE", None)
+    assert _rel(sp.apply(f), xo) <= TOL
+    sp.close()
+
+
+def test_sweep_shape_is_timed_at_setup_for_long_chains(spike, oracle, torch_cuda):
+    """K > 64 and chains of >= 8192 rows: the first setup of a shape times the candidate sweep shapes on the real factors and keeps
+    the fastest (a refactorisation keeps the choice); option sweep_autotune = off pins the base shape.  Same result to rounding."""
+    torch = torch_cuda
+    N, K = 2 ** 21, 128
+    band = spike.gen_band_device(N, K, seed=7, delta=1.2)
+    u = torch.ones(N, dtype=torch.float64, device="cuda")
+    sp = spike.Spike().setup_band(band)
+    assert "sweep shape =" in sp.view() and sp.info().chains_local * 8192 <= N
+    b = sp.matvec(u)
+    x = sp.apply(b)
+    assert float((x - u).abs().max()) <= 1e-10
+    t1 = sp.info().setup_ms
+    sp.setup_band(band)                       # refactorisation: no second timing
+    assert sp.info().setup_ms < t1 and "sweep shape =" in sp.view()
+    x2 = sp.apply(b)
+    assert torch.equal(x, x2)
+    off = spike.Spike()
+    off.set_option("sweep_autotune", "off")
+    off.setup_band(band)
+    assert "sweep shape =" not in off.view()
+    xo = off.apply(b)
+    assert float((x - xo).abs().max()) <= 1e-12

@@ -15,7 +15,7 @@ band = S.gen_band_device(N, K, seed=12345, delta=1.2)
 u = torch.ones(N, dtype=torch.float64, device="cuda")
 hs = []
 for name, opts in variants:
-    env = {k[4:]: v for k, v in opts.items() if k.startswith("ENV.")}
+    env = {k[4:]: v.replace(";", ",") for k, v in opts.items() if k.startswith("ENV.")}   # (";" stands for "," inside a value)
     for k, v in env.items(): os.environ[k] = v
     sp = S.Spike(partitions=P)
     for k, v in opts.items():
